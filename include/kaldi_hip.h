@@ -1,0 +1,292 @@
+/* kaldi_hip.h -- C ABI of libkaldi_hip.so, the MI355X (gfx950) device layer of the nnet1 hot path.
+ *
+ * It replaces, for one GPU per process, everything the reference's cudamatrix layer obtained
+ * from outside its own C++:
+ *   - the kernel wrappers of   src/cudamatrix/cu-kernels-ansi.h:33-94   (cudaI32_* / cudaF_*)
+ *   - the RNG wrappers of      src/cudamatrix/cu-randkernels-ansi.h:33-35
+ *   - cuBLAS sgemm             src/cudamatrix/cu-matrix-inl.h:860-907
+ *   - the CUDA runtime calls   src/cudamatrix/cu-matrix-inl.h:96-310, cu-vector-inl.h:64-200,
+ *                              cu-stlvector-inl.h:64-145, cu-device.cc:56-210
+ *
+ * Conventions (differences from the reference ABI are deliberate):
+ *   - every entry point returns int: 0 on success, otherwise a hipError_t value (or one of the
+ *     KH_ERR_* codes below); hipK_error_string() turns it into text.  The reference returned
+ *     void and polled cudaGetLastError() afterwards (cu-common.h:35-42).
+ *   - no `dim3 Gr, dim3 Bl`: launch geometry is chosen inside the library for CDNA4.
+ *   - the first argument is the stream (a hipStream_t passed as void*; NULL = the library's
+ *     default stream, see hipK_default_stream()).  Nothing synchronises implicitly except the
+ *     functions documented as blocking.
+ *   - all data pointers are device pointers owned by the caller unless the name says `host`.
+ *   - matrices are row-major; element (r,c) of a matrix with MatrixDim d lives at r*d.stride+c
+ *     (cu-matrixdim.h:41-45).  Strides are in elements.
+ *   - only float (`hipF_`) and int32 (`hipI32_`) are provided: no file of the reference's nnet1
+ *     path instantiates CuMatrix<double> (BaseFloat = float, base/kaldi-types.h:27).
+ *   - arithmetic notes that matter for parity are written at each entry point.
+ */
+#ifndef KALDI_AMD_INCLUDE_KALDI_HIP_H_
+#define KALDI_AMD_INCLUDE_KALDI_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* same layout as the reference's MatrixDim (cudamatrix/cu-matrixdim.h:41-45) */
+#ifndef KALDI_AMD_MATRIXDIM_DEFINED
+#define KALDI_AMD_MATRIXDIM_DEFINED
+typedef struct MatrixDim_ {
+  int32_t rows;
+  int32_t cols;
+  int32_t stride;
+} MatrixDim;
+#endif
+
+typedef void *khStream_t; /* hipStream_t */
+
+enum {
+  KH_OK = 0,
+  KH_ERR_INVALID_ARG = 100001, /* shape / pointer check failed before any launch */
+  KH_ERR_NOT_INITIALISED = 100002,
+  KH_ERR_COMM = 100003,        /* RCCL failure, see hipK_error_string */
+  KH_ERR_TOO_LARGE = 100004
+};
+
+enum { KH_NO_TRANS = 111, KH_TRANS = 112 }; /* values of kNoTrans / kTrans (matrix/matrix-common.h) */
+
+/* ------------------------------------------------------------------------------------------
+ * Device / runtime   (replaces cu-device.cc:56-210 and the cudaMalloc/cudaMemcpy call sites)
+ * ------------------------------------------------------------------------------------------ */
+
+/* Select a GPU and create the library's default stream.  device_id < 0 picks the visible GPU
+ * with the most free memory (cu-device.cc:62-118); otherwise that ordinal (SelectGpuId,
+ * cu-device.cc:136-175).  Idempotent for the same device. */
+int hipK_init(int device_id);
+int hipK_shutdown(void);
+int hipK_active_device(int *device_id);
+int hipK_device_count(int *count);
+int hipK_mem_info(size_t *free_bytes, size_t *total_bytes); /* cuMemGetInfo, cu-device.cc:210 */
+int hipK_default_stream(khStream_t *stream);
+int hipK_stream_create(khStream_t *stream);
+int hipK_stream_destroy(khStream_t stream);
+int hipK_stream_synchronize(khStream_t stream); /* blocking */
+int hipK_device_synchronize(void);              /* blocking */
+const char *hipK_error_string(int status);
+/* compute units, wave size, gcn arch name ("gfx950...") of the active device */
+int hipK_device_props(int *num_cu, int *wave_size, char *arch_name, size_t arch_name_len);
+
+/* cudaMallocPitch (cu-matrix-inl.h:108): rows x cols floats, row pitch rounded up so that every
+ * row starts 256-byte aligned; *stride_elems receives the pitch in elements.  Not zeroed. */
+int hipK_malloc_pitch(void **ptr, int32_t *stride_elems, int32_t rows, int32_t cols, size_t elem_size);
+int hipK_malloc(void **ptr, size_t bytes);          /* cudaMalloc, cu-vector-inl.h:74 */
+int hipK_free(void *ptr);
+int hipK_malloc_host(void **ptr, size_t bytes);     /* pinned host staging buffer */
+int hipK_free_host(void *ptr);
+int hipK_memset_async(khStream_t s, void *ptr, int value, size_t bytes); /* cudaMemset */
+/* cudaMemcpy2D (cu-matrix-inl.h:155-284).  kind: 0 h2d, 1 d2h, 2 d2d.  Pitches and width in bytes.
+ * h2d/d2h block until the copy has completed; d2d is asynchronous on the stream. */
+int hipK_memcpy_2d(khStream_t s, void *dst, size_t dpitch, const void *src, size_t spitch,
+                   size_t width_bytes, size_t height, int kind);
+int hipK_memcpy(khStream_t s, void *dst, const void *src, size_t bytes, int kind);
+
+/* ------------------------------------------------------------------------------------------
+ * int32 kernels
+ * ------------------------------------------------------------------------------------------ */
+/* cudaI32_set_const (cu-kernels-ansi.h:33) */
+int hipI32_set_const(khStream_t s, int32_t *mat, int32_t value, MatrixDim d);
+
+/* ------------------------------------------------------------------------------------------
+ * float kernels: CuMatrix   (cu-kernels-ansi.h:44-67; kernels cu-kernels.cu:120-454)
+ * ------------------------------------------------------------------------------------------ */
+int hipF_set_const(khStream_t s, float *mat, float value, MatrixDim d);
+int hipF_part_set_const(khStream_t s, float *mat, float value, MatrixDim d, int32_t ro, int32_t r,
+                        int32_t co, int32_t c);
+int hipF_binarize(khStream_t s, float *mat, float thres, MatrixDim d);
+int hipF_add_const(khStream_t s, float *mat, float value, MatrixDim d);
+int hipF_power(khStream_t s, float *mat, float pow, MatrixDim d);
+int hipF_round(khStream_t s, float *mat, MatrixDim d);
+int hipF_scale(khStream_t s, float *mat, float value, MatrixDim d);
+int hipF_apply_floor(khStream_t s, float *mat, float value, MatrixDim d);
+int hipF_apply_truncate(khStream_t s, float *mat, float low, float high, MatrixDim d);
+int hipF_apply_log(khStream_t s, float *mat, MatrixDim d);
+int hipF_apply_exp(khStream_t s, float *mat, MatrixDim d);
+/* mat and A share d (the reference asserts equal stride, cu-matrix-inl.h:545) */
+int hipF_mul_elements(khStream_t s, float *mat, const float *A, MatrixDim d);
+int hipF_div_elements(khStream_t s, float *mat, const float *A, MatrixDim d);
+int hipF_mul_cols_vec(khStream_t s, float *mat, const float *scale, MatrixDim d);
+int hipF_mul_rows_vec(khStream_t s, float *mat, const float *scale, MatrixDim d);
+/* multiply by the float reciprocal 1.0f/v, as the reference kernels do (cu-kernels.cu:304,326) */
+int hipF_div_cols_vec(khStream_t s, float *mat, const float *vec_div, MatrixDim d);
+int hipF_div_rows_vec(khStream_t s, float *mat, const float *vec_div, MatrixDim d);
+/* dst = alpha*A + beta*dst; A and dst share d.  Also serves CuVector::AddVec (rows = 1). */
+int hipF_add_mat(khStream_t s, float alpha, const float *A, float beta, float *dst, MatrixDim d);
+int hipF_part_add_mat(khStream_t s, float alpha, const float *A, MatrixDim da, int32_t ro, int32_t co,
+                      float beta, float *dst, MatrixDim d);
+int hipF_add_vec_to_cols(khStream_t s, float alpha, const float *col, float beta, float *dst, MatrixDim d);
+int hipF_add_vec_to_rows(khStream_t s, float alpha, const float *row, float beta, float *dst, MatrixDim d);
+int hipF_add_vec_to_partial_rows(khStream_t s, float alpha, int32_t offset, const float *row, int32_t dim,
+                                 float beta, float *dst, MatrixDim d);
+/* dst = log(exp(A)+exp(dst)), evaluated in double like cu-kernels.cu:362-380 */
+int hipF_log_add_exp_mat(khStream_t s, const float *A, float *dst, MatrixDim d);
+/* rows whose L2 norm exceeds bound are rescaled to it (cu-kernels.cu:431-454; double accumulation) */
+int hipF_apply_row_l2upperbound(khStream_t s, float *mat, float bound, MatrixDim d);
+
+/* ------------------------------------------------------------------------------------------
+ * float kernels: CuVector   (cu-kernels-ansi.h:71-73; host slab loops cu-vector-inl.h:443-529)
+ * The reference launched one 256-row (256-column) slab per call and looped on the host; here one
+ * call reduces the whole matrix:  vec = alpha * sum + beta * vec.
+ * ------------------------------------------------------------------------------------------ */
+/* vec[c] = alpha * sum_r mat[r,c] + beta * vec[c]   (CuVector::AddRowSumMat).  fp32 accumulation. */
+int hipF_add_row_sum_mat(khStream_t s, float alpha, const float *mat, MatrixDim d, float beta, float *vec);
+/* vec[r] = alpha * sum_c mat[r,c] + beta * vec[r]   (CuVector::AddColSumMat) */
+int hipF_add_col_sum_mat(khStream_t s, float alpha, const float *mat, MatrixDim d, float beta, float *vec);
+int hipF_invert_elements(khStream_t s, float *data, MatrixDim d);
+
+/* ------------------------------------------------------------------------------------------
+ * float kernels: cu:: functions   (cu-kernels-ansi.h:78-94)
+ * ------------------------------------------------------------------------------------------ */
+int hipF_relu(khStream_t s, float *y, const float *x, MatrixDim d);
+int hipF_diff_relu(khStream_t s, float *eout, const float *e, const float *y, MatrixDim d);
+int hipF_softrelu(khStream_t s, float *y, const float *x, MatrixDim d);
+int hipF_diff_softrelu(khStream_t s, float *eout, const float *e, const float *x, MatrixDim d);
+/* y = 1/(1+exp(-x)) (cu-kernels.cu:577-585).  y, x (and eout, e, y below) share d. */
+int hipF_sigmoid(khStream_t s, float *y, const float *x, MatrixDim d);
+/* eout = y*(1-y)*e (cu-kernels.cu:590-596) */
+int hipF_diff_sigmoid(khStream_t s, float *eout, const float *e, const float *y, MatrixDim d);
+/* Row softmax with max subtraction in ONE pass over HBM: y[r,:] = exp(x[r,:]-max_r)/sum.
+ * Replaces the whole of cu::Softmax (cu-math-inl.h:209-251: FindRowMaxId + softmax_part +
+ * AddColSumMat + DivRowsVec) as well as the disabled cuda_softmax (cu-kernels.cu:601-621).
+ * The sum is accumulated in fp32 (like CPU ApplySoftMax, matrix/kaldi-vector.cc:678-685) and
+ * every element is multiplied by the fp32 reciprocal of the sum.  y may alias x. */
+int hipF_softmax(khStream_t s, float *y, const float *x, MatrixDim d);
+/* Y = exp(X - X[r, vec_ids[r]])  (cu-kernels.cu:751-759); kept for callers that build softmax from parts */
+int hipF_softmax_part(khStream_t s, const float *X, const int32_t *vec_ids, float *Y, MatrixDim d);
+int hipF_regularize_l1(khStream_t s, float *wei, float *grad, float l1, float lr, MatrixDim d);
+/* vec_id[r] = argmax_c mat[r,c]; vec_val[r] (may be NULL) = that maximum.  One call covers all
+ * columns (the reference looped over 256-column slabs, cu-math-inl.h:297-332).  Ties resolve to the
+ * LOWEST column index, which is what the reference's CPU path does (strict '<', cu-math-inl.h:343);
+ * a row whose elements are all <= -1e21 (or NaN) yields -1, as there. */
+int hipF_find_row_max_id(khStream_t s, const float *mat, float *vec_val, int32_t *vec_id, MatrixDim d);
+/* vec_log_post[r] = log(max(mat[r,tgt[r]], 1e-20)); mat[r,tgt[r]] -= 1  (cu-kernels.cu:733-745) */
+int hipF_diff_xent(khStream_t s, const int32_t *vec_tgt, float *mat_net_out, float *vec_log_post, MatrixDim d);
+/* y[r,:] = x[copy_from[r],:] for r < d_out.rows (cu-kernels.cu:661-669) */
+int hipF_randomize(khStream_t s, float *y, const float *x, const int32_t *copy_from, MatrixDim d_out,
+                   MatrixDim d_in);
+/* splice: y[r, k*D+c] = x[clamp(r+off[k], 0, rows-1), c]  (cu-kernels.cu:627-638) */
+int hipF_expand(khStream_t s, float *y, const float *x, const int32_t *off, MatrixDim d_out, MatrixDim d_in);
+/* column gather: y[r,c] = x[r, copy_from[c]]; an index outside [0, d_in.cols) writes +inf
+ * (cu-kernels.cu:644-656) */
+int hipF_copy(khStream_t s, float *y, const float *x, const int32_t *copy_from, MatrixDim d_out, MatrixDim d_in);
+
+/* ------------------------------------------------------------------------------------------
+ * RNG   (cu-randkernels-ansi.h:33-35; kernels cu-randkernels.cu:44-120)
+ * Per-element HybridTaus state in four uint32 arrays laid out like the matrix (rows*stride);
+ * bit-for-bit the reference generator, so equal seeds give equal draws.
+ * ------------------------------------------------------------------------------------------ */
+int hipF_rand(khStream_t s, float *mat, uint32_t *z1, uint32_t *z2, uint32_t *z3, uint32_t *z4, MatrixDim d);
+int hipF_gauss_rand(khStream_t s, float *mat, uint32_t *z1, uint32_t *z2, uint32_t *z3, uint32_t *z4, MatrixDim d);
+/* states = probs > rand ? 1 : 0 */
+int hipF_binarize_probs(khStream_t s, float *states, const float *probs, const float *rand, MatrixDim d);
+/* Fused forms used by CuRand: draw and apply in one pass, state updated in place, no temporary
+ * matrix.  Same draws as hipF_rand / hipF_gauss_rand followed by binarize_probs / add_mat
+ * (cu-rand-inl.h:139-177). */
+int hipF_binarize_probs_rand(khStream_t s, float *states, const float *probs, uint32_t *z1, uint32_t *z2,
+                             uint32_t *z3, uint32_t *z4, MatrixDim d);
+int hipF_add_gauss_noise(khStream_t s, float *mat, float gscale, uint32_t *z1, uint32_t *z2, uint32_t *z3,
+                         uint32_t *z4, MatrixDim d);
+
+/* ------------------------------------------------------------------------------------------
+ * GEMM   (replaces cublasSgemm at cu-matrix-inl.h:860-907)
+ * C(MxN) = alpha * op(A) * op(B) + beta * C, row-major, leading dimensions in elements.
+ * op(A) is MxK, op(B) is KxN.  fp32 in, fp32 accumulate on the matrix cores
+ * (v_mfma_f32_32x32x2_f32); products are summed in a fixed, run-to-run reproducible order.
+ * beta == 0 never reads C (so C may hold NaNs).
+ * ------------------------------------------------------------------------------------------ */
+int hipF_gemm(khStream_t s, int transA, int transB, int32_t M, int32_t N, int32_t K, float alpha,
+              const float *A, int32_t lda, const float *B, int32_t ldb, float beta, float *C, int32_t ldc);
+
+/* Bytes of scratch hipF_gemm_ex / the fused entry points want for a given problem; the library
+ * keeps one such workspace per process and grows it on demand (blocking), so callers only need
+ * this to pre-size it before capturing a graph. */
+int hipK_reserve_workspace(size_t bytes);
+
+/* ------------------------------------------------------------------------------------------
+ * Fused entry points of the nnet1 hot path.  Each one is arithmetic-for-arithmetic the sequence
+ * of reference calls named in its comment; they exist so that the activations make one trip
+ * through HBM instead of three or four.
+ * ------------------------------------------------------------------------------------------ */
+enum { KH_ACT_NONE = 0, KH_ACT_SIGMOID = 1, KH_ACT_SOFTMAX = 2 };
+
+/* out(NxO) = act( bias(row, O) + in(NxI) * W(OxI)^T )
+ *   = BiasedLinearity::PropagateFnc (nnet-biasedlinearity.h:58-63) [+ Sigmoid::PropagateFnc
+ *     (nnet-activation.h:207-210) | Softmax::PropagateFnc (:233-236)]
+ *   = Rbm::PropagateFnc (nnet-rbm.h:136-145)
+ * trans_w = KH_NO_TRANS computes in * W instead (W is IxO): Rbm::Reconstruct (nnet-rbm.h:158-176). */
+int hipF_affine_forward(khStream_t s, int act, int trans_w, int32_t N, int32_t O, int32_t I, const float *in,
+                        int32_t ldin, const float *W, int32_t ldw, const float *bias, float *out, int32_t ldout);
+
+/* eout(NxI) = e(NxO) * W(OxI) [ .* y .* (1-y) when y != NULL ]
+ *   = BiasedLinearity::BackpropagateFnc (nnet-biasedlinearity.h:65-69) followed by
+ *     Sigmoid::BackpropagateFnc of the layer below (nnet-activation.h:212-218). */
+int hipF_affine_backward(khStream_t s, int32_t N, int32_t O, int32_t I, const float *e, int32_t lde,
+                         const float *W, int32_t ldw, const float *y, int32_t ldy, float *eout, int32_t ldeout);
+
+/* BiasedLinearity::Update (nnet-biasedlinearity.h:71-102) without the L1 / max-norm options:
+ *   corr  = gscale * e^T * in + momentum * corr        (corr OxI; gscale = 1 or 1/N)
+ *   bcorr = gscale * colsum(e) + momentum * bcorr
+ *   W     = (1 - l2) * W - lr * corr                   (l2 = lr * l2_penalty * N, 0 to disable)
+ *   b     = b - lr * bcorr
+ * The weight pass is the epilogue of the gradient GEMM: W and corr are read and written once.
+ * corr / bcorr may be NULL only when momentum == 0 (the gradient is then not stored). */
+int hipF_affine_update(khStream_t s, int32_t N, int32_t O, int32_t I, const float *e, int32_t lde,
+                       const float *in, int32_t ldin, float gscale, float momentum, float lr, float l2,
+                       float *W, int32_t ldw, float *corr, int32_t ldcorr, float *bias, float *bcorr);
+
+/* Xent::EvalVec on the device (nnet-loss.cc:59-94 = cu::FindRowMaxId + host compare +
+ * cu::DiffXent + host sum), one pass over the posteriors:
+ *   diff = post - onehot(tgt)           (diff may alias post)
+ *   log_post[r] = log(max(post[r,tgt[r]], 1e-20))        (may be NULL)
+ *   max_id[r]   = argmax_c post[r,c], lowest index on ties (may be NULL)
+ *   counters[0] += #rows with max_id == tgt   (int64)
+ *   counters[1] += #rows                      (int64)
+ *   loss[0]     -= sum_r log_post[r]          (double, summed in row order)
+ * counters / loss live on the device and are read back by the caller when it reports. */
+int hipF_xent_eval(khStream_t s, const float *post, const int32_t *tgt, float *diff, float *log_post,
+                   int32_t *max_id, long long *counters, double *loss, MatrixDim d);
+
+/* MseProgress::Eval / Mse::Eval (nnet-loss.cc:123-194): diff = a - b (may be NULL);
+ * loss[0] += 0.5 * sum (a-b)^2 (double on device); per-row sums in row_sq (may be NULL). */
+int hipF_mse_eval(khStream_t s, const float *a, const float *b, float *diff, float *row_sq, double *loss,
+                  MatrixDim d);
+
+/* Rbm::RbmUpdate (nnet-rbm.h:178-223):
+ *   dW = mom*dW - (lr/N) neg_hid^T neg_vis + (lr/N) pos_hid^T pos_vis - lr*l2*W ;  W += dW
+ *   da = mom*da - (lr/N) colsum(neg_vis) + (lr/N) colsum(pos_vis) ;              a += da
+ *   db likewise with hid. */
+int hipF_rbm_update(khStream_t s, int32_t N, int32_t H, int32_t V, const float *pos_vis, int32_t ldpv,
+                    const float *pos_hid, int32_t ldph, const float *neg_vis, int32_t ldnv,
+                    const float *neg_hid, int32_t ldnh, float lr, float momentum, float l2, float *W,
+                    int32_t ldw, float *dW, int32_t lddw, float *vis_bias, float *dvis_bias,
+                    float *hid_bias, float *dhid_bias);
+
+/* ------------------------------------------------------------------------------------------
+ * Multi-GPU (no counterpart in the reference, which is single-GPU: cu-device.cc).
+ * One process per GPU; RCCL over xGMI.  The unique id is created on rank 0 and handed to the
+ * other ranks by the caller (file, socket, torch.distributed store ...).
+ * ------------------------------------------------------------------------------------------ */
+#define KH_COMM_ID_BYTES 128
+int hipK_comm_get_unique_id(unsigned char id[KH_COMM_ID_BYTES]);
+int hipK_comm_init(const unsigned char id[KH_COMM_ID_BYTES], int rank, int nranks);
+int hipK_comm_destroy(void);
+int hipK_comm_rank(int *rank, int *nranks);
+/* in-place sum all-reduce of count floats on stream s (ordered with the kernels on s) */
+int hipF_allreduce_sum(khStream_t s, float *buf, size_t count);
+int hipK_allreduce_sum_f64(khStream_t s, double *buf, size_t count);
+int hipK_allreduce_sum_i64(khStream_t s, long long *buf, size_t count);
+int hipK_comm_barrier(khStream_t s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KALDI_AMD_INCLUDE_KALDI_HIP_H_ */

@@ -1,0 +1,105 @@
+// Multi-GPU collectives: one process per GPU, RCCL over xGMI.  The reference has no
+// counterpart (single GPU, src/cudamatrix/cu-device.cc); synchronous data-parallel training
+// sums per-layer gradients with these calls, ordered on the same stream as the kernels.
+#include <rccl/rccl.h>
+#include <string.h>
+
+#include "common.h"
+
+namespace {
+struct Comm {
+  ncclComm_t comm = nullptr;
+  int rank = 0, nranks = 1;
+};
+Comm &comm() {
+  static Comm c;
+  return c;
+}
+int nccl_fail(ncclResult_t r, const char *what) {
+  snprintf(kh::ctx().last_msg, sizeof(kh::ctx().last_msg), "%s: %s", what, ncclGetErrorString(r));
+  return KH_ERR_COMM;
+}
+}  // namespace
+
+#define KH_NCCL(call)                                  \
+  do {                                                 \
+    ncclResult_t r__ = (call);                         \
+    if (r__ != ncclSuccess) return nccl_fail(r__, #call); \
+  } while (0)
+
+static_assert(sizeof(ncclUniqueId) == KH_COMM_ID_BYTES, "unique id size");
+
+KH_EXPORT int hipK_comm_get_unique_id(unsigned char id[KH_COMM_ID_BYTES]) {
+  KH_REQUIRE(id != nullptr);
+  ncclUniqueId uid;
+  KH_NCCL(ncclGetUniqueId(&uid));
+  memcpy(id, &uid, KH_COMM_ID_BYTES);
+  return KH_OK;
+}
+
+KH_EXPORT int hipK_comm_init(const unsigned char id[KH_COMM_ID_BYTES], int rank, int nranks) {
+  KH_CHECK_INIT();
+  KH_REQUIRE(id != nullptr && nranks >= 1 && rank >= 0 && rank < nranks);
+  Comm &c = comm();
+  if (c.comm) {
+    KH_NCCL(ncclCommDestroy(c.comm));
+    c.comm = nullptr;
+  }
+  ncclUniqueId uid;
+  memcpy(&uid, id, KH_COMM_ID_BYTES);
+  KH_NCCL(ncclCommInitRank(&c.comm, nranks, uid, rank));
+  c.rank = rank;
+  c.nranks = nranks;
+  return KH_OK;
+}
+
+KH_EXPORT int hipK_comm_destroy(void) {
+  Comm &c = comm();
+  if (c.comm) {
+    KH_NCCL(ncclCommDestroy(c.comm));
+    c.comm = nullptr;
+  }
+  c.rank = 0;
+  c.nranks = 1;
+  return KH_OK;
+}
+
+KH_EXPORT int hipK_comm_rank(int *rank, int *nranks) {
+  if (rank) *rank = comm().rank;
+  if (nranks) *nranks = comm().nranks;
+  return KH_OK;
+}
+
+template <typename T>
+static int allreduce(khStream_t s, T *buf, size_t count, ncclDataType_t dt) {
+  KH_CHECK_INIT();
+  if (count == 0) return KH_OK;
+  KH_REQUIRE(buf != nullptr);
+  Comm &c = comm();
+  if (c.nranks == 1) return KH_OK;  // a single replica already holds the sum
+  if (!c.comm) return KH_ERR_NOT_INITIALISED;
+  KH_NCCL(ncclAllReduce(buf, buf, count, dt, ncclSum, c.comm, kh::pick(s)));
+  return KH_OK;
+}
+
+KH_EXPORT int hipF_allreduce_sum(khStream_t s, float *buf, size_t count) {
+  return allreduce<float>(s, buf, count, ncclFloat32);
+}
+KH_EXPORT int hipK_allreduce_sum_f64(khStream_t s, double *buf, size_t count) {
+  return allreduce<double>(s, buf, count, ncclFloat64);
+}
+KH_EXPORT int hipK_allreduce_sum_i64(khStream_t s, long long *buf, size_t count) {
+  return allreduce<long long>(s, buf, count, ncclInt64);
+}
+
+KH_EXPORT int hipK_comm_barrier(khStream_t s) {
+  KH_CHECK_INIT();
+  Comm &c = comm();
+  if (c.nranks == 1) return hipK_stream_synchronize(s);
+  if (!c.comm) return KH_ERR_NOT_INITIALISED;
+  void *ws;
+  int rc = kh::ensure_workspace(256, &ws);
+  if (rc != KH_OK) return rc;
+  KH_NCCL(ncclAllReduce(ws, ws, 1, ncclFloat32, ncclSum, c.comm, kh::pick(s)));
+  return hipK_stream_synchronize(s);
+}

@@ -1,0 +1,117 @@
+// Shared helpers of libkaldi_hip.so (device layer of the nnet1 hot path, gfx950 only).
+#ifndef KALDI_AMD_CSRC_HIP_COMMON_H_
+#define KALDI_AMD_CSRC_HIP_COMMON_H_
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "kaldi_hip.h"
+
+#define KH_EXPORT extern "C" __attribute__((visibility("default")))
+
+namespace kh {
+
+// Process-wide state: one GPU, one default stream, one scratch workspace.
+struct Context {
+  bool initialised = false;
+  int device = -1;
+  hipStream_t stream = nullptr;
+  int num_cu = 0;
+  void *workspace = nullptr;
+  size_t workspace_bytes = 0;
+  char last_msg[256] = {0};
+};
+Context &ctx();
+
+// Stream to launch on: the caller's, or the library default when it passed NULL.
+inline hipStream_t pick(khStream_t s) { return s ? (hipStream_t)s : ctx().stream; }
+
+// Grows the shared workspace to at least `bytes` (blocking when it has to reallocate).
+int ensure_workspace(size_t bytes, void **ptr);
+
+inline int launch_status() {
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? KH_OK : (int)e;
+}
+
+inline bool aligned16(const void *p) { return (((uintptr_t)p) & 15u) == 0; }
+
+// d describes a matrix that a kernel may index: reject anything a kernel would fault on.
+inline bool dim_ok(MatrixDim d) { return d.rows >= 0 && d.cols >= 0 && d.stride >= d.cols; }
+
+}  // namespace kh
+
+#define KH_CHECK_INIT()                                      \
+  do {                                                       \
+    if (!kh::ctx().initialised) {                            \
+      int st__ = hipK_init(-1);                              \
+      if (st__ != KH_OK) return st__;                        \
+    }                                                        \
+  } while (0)
+
+#define KH_REQUIRE(cond)                                                                   \
+  do {                                                                                     \
+    if (!(cond)) {                                                                         \
+      snprintf(kh::ctx().last_msg, sizeof(kh::ctx().last_msg), "%s: requirement failed: %s", \
+               __func__, #cond);                                                           \
+      return KH_ERR_INVALID_ARG;                                                           \
+    }                                                                                      \
+  } while (0)
+
+#define KH_HIP(call)                           \
+  do {                                         \
+    hipError_t e__ = (call);                   \
+    if (e__ != hipSuccess) return (int)e__;    \
+  } while (0)
+
+// ---- device-side helpers -------------------------------------------------------------------
+#ifdef __HIPCC__
+namespace kh {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// Block-wide reductions for blocks of up to 1024 threads (16 waves); `red` holds 16 floats.
+__device__ __forceinline__ float block_sum(float v, float *red) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  v = wave_sum(v);
+  __syncthreads();
+  if (lane == 0) red[wid] = v;
+  __syncthreads();
+  float t = 0.f;
+  for (int i = 0; i < nw; ++i) t += red[i];  // fixed order: every thread gets the same bits
+  return t;
+}
+__device__ __forceinline__ float block_max(float v, float *red) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  v = wave_max(v);
+  __syncthreads();
+  if (lane == 0) red[wid] = v;
+  __syncthreads();
+  float t = red[0];
+  for (int i = 1; i < nw; ++i) t = fmaxf(t, red[i]);
+  return t;
+}
+
+// 1/(1+exp(-x)) in fp32.  expf() here is the correctly scaled library call (not the fast
+// intrinsic) so results stay within a few ulp of the reference's double evaluation.
+__device__ __forceinline__ float sigmoidf(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+}  // namespace kh
+#endif  // __HIPCC__
+
+#endif  // KALDI_AMD_CSRC_HIP_COMMON_H_

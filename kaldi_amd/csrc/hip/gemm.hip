@@ -1,0 +1,646 @@
+// fp32 GEMM on the CDNA4 matrix cores (v_mfma_f32_32x32x2_f32) with LDS-staged tiles, and the
+// fused affine forward / backward / update entry points built on it.  Replaces the single
+// cublasSgemm call site of the reference (src/cudamatrix/cu-matrix-inl.h:860-907) and the
+// element-wise passes the reference ran around it (nnet/nnet-biasedlinearity.h:58-102,
+// nnet/nnet-activation.h:207-218, nnet/nnet-rbm.h:136-223).
+//
+// Shape of the problem on this path: M = minibatch (256) for forward/backward, so a plain
+// one-tile-per-block decomposition leaves most of the 256 CUs idle.  The K dimension is
+// therefore split over workgroups (split-K); each split writes an fp32 partial slab and the
+// element-wise kernel that has to run next anyway (bias + sigmoid, softmax, y(1-y) scaling,
+// alpha/beta) sums the slabs in a fixed order -- no atomics, bit-reproducible.
+//
+// Kernel structure (one workgroup = 4 waves = 256 threads, one output tile BM x BN):
+//   global --dwordx4--> VGPR (next K-tile, issued before the MFMAs of the current one)
+//          --ds_write_b128--> LDS double buffer (one barrier per K-tile)
+//          --ds_read_b128 / ds_read_b32--> MFMA operands, 32x32 accumulators in registers.
+// Operand k-order inside a group of 8 is permuted (lane half h, step j uses k = 8g + 4h + j)
+// so that a K-contiguous operand is fetched with one 16-byte LDS read per 4 MFMAs; both
+// operands use the same permutation, so the sum is over the same k set.
+#include <stdlib.h>
+#include <string.h>
+
+#include "common.h"
+
+namespace kh {
+int softmax_slabs_launch(hipStream_t st, float *y, int ldy, const float *x, int ldx, int nslab, size_t slab_stride,
+                         const float *bias, int rows, int cols);
+}
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+enum Epi {
+  EPI_AXPBY = 0,   // C = alpha*acc + beta*C
+  EPI_SLAB = 1,    // slab[ks] = acc                     (split-K partial)
+  EPI_BIAS_ACT = 2,// C = act(bias[col] + acc)
+  EPI_DSIG = 3,    // C = acc * y * (1 - y)
+  EPI_UPDATE = 4,  // corr = g*acc + mom*corr ; W = W - l2*W - lr*corr
+  EPI_RBM = 5      // dW = g*acc + dW - lrl2*W ; W += dW
+};
+
+struct GemmParams {
+  const float *A, *B;
+  int lda, ldb;
+  int M, N, K;
+  int splitk, k_per_split;
+  int tiles_m, tiles_n;
+  float alpha, beta;
+  float *C;
+  int ldc;
+  size_t slab_stride;
+  const float *bias;
+  const float *y;
+  int ldy;
+  float *W;
+  int ldw;
+  float lr, l2, mom;
+  int act;
+};
+
+template <int EPI>
+__device__ __forceinline__ void epi_store(const GemmParams &p, int row, int col, float acc, int ks) {
+  if (EPI == EPI_SLAB) {
+    p.C[(size_t)ks * p.slab_stride + (size_t)row * p.ldc + col] = acc;
+  } else if (EPI == EPI_AXPBY) {
+    float *c = p.C + (size_t)row * p.ldc + col;
+    *c = (p.beta == 0.f) ? p.alpha * acc : p.alpha * acc + p.beta * *c;
+  } else if (EPI == EPI_BIAS_ACT) {
+    float v = acc + p.bias[col];
+    if (p.act == KH_ACT_SIGMOID) v = kh::sigmoidf(v);
+    p.C[(size_t)row * p.ldc + col] = v;
+  } else if (EPI == EPI_DSIG) {
+    const float yv = p.y[(size_t)row * p.ldy + col];
+    p.C[(size_t)row * p.ldc + col] = yv * (1.0f - yv) * acc;
+  } else if (EPI == EPI_UPDATE) {
+    float c = p.alpha * acc;
+    if (p.mom != 0.f) c += p.mom * p.C[(size_t)row * p.ldc + col];
+    if (p.C) p.C[(size_t)row * p.ldc + col] = c;
+    float *w = p.W + (size_t)row * p.ldw + col;
+    float wv = *w;
+    if (p.l2 != 0.f) wv = -p.l2 * wv + wv;
+    *w = -p.lr * c + wv;
+  } else if (EPI == EPI_RBM) {
+    float *w = p.W + (size_t)row * p.ldw + col;
+    float *dw = p.C + (size_t)row * p.ldc + col;
+    const float wv = *w;
+    float d = p.alpha * acc + *dw;
+    d = -p.l2 * wv + d;
+    *dw = d;
+    *w = d + wv;
+  }
+}
+
+// BM x BN output tile, BK-deep K-tiles, WAVES_M x WAVES_N waves (always 4 here).
+// A_KMAJOR: A(m,k) at A[m*lda+k] (k contiguous), otherwise A[k*lda+m].  Same for B with n.
+// VEC: every row base is 16-byte aligned and leading dimensions are multiples of 4 floats.
+template <int BM, int BN, int BK, bool A_KMAJOR, bool B_KMAJOR, int EPI, bool VEC>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
+  constexpr int NT = 256;
+  constexpr int WAVES_M = 2, WAVES_N = 2;
+  constexpr int TM = BM / (WAVES_M * 32), TN = BN / (WAVES_N * 32);
+  constexpr int PA = A_KMAJOR ? (BK + 4) : BM;         // LDS pitch of the A image (floats)
+  constexpr int PB = B_KMAJOR ? (BK + 4) : BN;
+  constexpr int A_ELEMS = A_KMAJOR ? BM * PA : BK * PA;
+  constexpr int B_ELEMS = B_KMAJOR ? BN * PB : BK * PB;
+  constexpr int A_UNITS = BM * BK / 4 / NT;            // float4 loads per thread per K-tile
+  constexpr int B_UNITS = BN * BK / 4 / NT;
+  static_assert(A_UNITS >= 1 && B_UNITS >= 1, "tile too small for 256 threads");
+
+  __shared__ __attribute__((aligned(16))) float lds[2 * (A_ELEMS + B_ELEMS)];
+
+  // ---- which tile: XCD-aware decode of the linear block id -----------------------------------
+  // Blocks b and b+8 run on the same XCD (same L2); give each XCD a contiguous run of tiles so
+  // that neighbours, which share the B (weight) panel, hit in that L2.
+  const int nblk = gridDim.x;
+  int L = blockIdx.x;
+  if ((nblk & 7) == 0) L = (L & 7) * (nblk >> 3) + (L >> 3);
+  const int mi = L % p.tiles_m;
+  L /= p.tiles_m;
+  const int ks = L % p.splitk;
+  const int ni = L / p.splitk;
+  const int m0 = mi * BM, n0 = ni * BN;
+  const int kbeg = ks * p.k_per_split;
+  const int kend = min(p.K, kbeg + p.k_per_split);
+  const int nkt = (kend - kbeg + BK - 1) / BK;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wid = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int wm0 = (wid / WAVES_N) * (TM * 32), wn0 = (wid % WAVES_N) * (TN * 32);
+
+  float4 ra[A_UNITS], rb[B_UNITS];
+
+  auto load_a = [&](int k0) {
+#pragma unroll
+    for (int u = 0; u < A_UNITS; ++u) {
+      const int unit = tid + u * NT;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (A_KMAJOR) {
+        const int row = unit / (BK / 4), kq = unit % (BK / 4);
+        const int m = m0 + row, k = k0 + kq * 4;
+        if (m < p.M && k < kend) {
+          const float *src = p.A + (size_t)m * p.lda + k;
+          if (VEC) {
+            v = *reinterpret_cast<const float4 *>(src);
+            if (k + 3 >= kend) {
+              if (k + 1 >= kend) v.y = 0.f;
+              if (k + 2 >= kend) v.z = 0.f;
+              v.w = 0.f;
+            }
+          } else {
+            v.x = src[0];
+            if (k + 1 < kend) v.y = src[1];
+            if (k + 2 < kend) v.z = src[2];
+            if (k + 3 < kend) v.w = src[3];
+          }
+        }
+      } else {
+        const int krow = unit / (BM / 4), mq = unit % (BM / 4);
+        const int k = k0 + krow, m = m0 + mq * 4;
+        if (k < kend && m < p.M) {
+          const float *src = p.A + (size_t)k * p.lda + m;
+          if (VEC) {
+            v = *reinterpret_cast<const float4 *>(src);
+          } else {
+            v.x = src[0];
+            if (m + 1 < p.M) v.y = src[1];
+            if (m + 2 < p.M) v.z = src[2];
+            if (m + 3 < p.M) v.w = src[3];
+          }
+        }
+      }
+      ra[u] = v;
+    }
+  };
+  auto load_b = [&](int k0) {
+#pragma unroll
+    for (int u = 0; u < B_UNITS; ++u) {
+      const int unit = tid + u * NT;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (B_KMAJOR) {
+        const int row = unit / (BK / 4), kq = unit % (BK / 4);
+        const int n = n0 + row, k = k0 + kq * 4;
+        if (n < p.N && k < kend) {
+          const float *src = p.B + (size_t)n * p.ldb + k;
+          if (VEC) {
+            v = *reinterpret_cast<const float4 *>(src);
+            if (k + 3 >= kend) {
+              if (k + 1 >= kend) v.y = 0.f;
+              if (k + 2 >= kend) v.z = 0.f;
+              v.w = 0.f;
+            }
+          } else {
+            v.x = src[0];
+            if (k + 1 < kend) v.y = src[1];
+            if (k + 2 < kend) v.z = src[2];
+            if (k + 3 < kend) v.w = src[3];
+          }
+        }
+      } else {
+        const int krow = unit / (BN / 4), nq = unit % (BN / 4);
+        const int k = k0 + krow, n = n0 + nq * 4;
+        if (k < kend && n < p.N) {
+          const float *src = p.B + (size_t)k * p.ldb + n;
+          if (VEC) {
+            v = *reinterpret_cast<const float4 *>(src);
+          } else {
+            v.x = src[0];
+            if (n + 1 < p.N) v.y = src[1];
+            if (n + 2 < p.N) v.z = src[2];
+            if (n + 3 < p.N) v.w = src[3];
+          }
+        }
+      }
+      rb[u] = v;
+    }
+  };
+  auto store_tiles = [&](int buf) {
+    float *As = lds + buf * (A_ELEMS + B_ELEMS);
+    float *Bs = As + A_ELEMS;
+#pragma unroll
+    for (int u = 0; u < A_UNITS; ++u) {
+      const int unit = tid + u * NT;
+      if (A_KMAJOR) {
+        const int row = unit / (BK / 4), kq = unit % (BK / 4);
+        *reinterpret_cast<float4 *>(As + row * PA + kq * 4) = ra[u];
+      } else {
+        const int krow = unit / (BM / 4), mq = unit % (BM / 4);
+        *reinterpret_cast<float4 *>(As + krow * PA + mq * 4) = ra[u];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < B_UNITS; ++u) {
+      const int unit = tid + u * NT;
+      if (B_KMAJOR) {
+        const int row = unit / (BK / 4), kq = unit % (BK / 4);
+        *reinterpret_cast<float4 *>(Bs + row * PB + kq * 4) = rb[u];
+      } else {
+        const int krow = unit / (BN / 4), nq = unit % (BN / 4);
+        *reinterpret_cast<float4 *>(Bs + krow * PB + nq * 4) = rb[u];
+      }
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  if (nkt > 0) {
+    load_a(kbeg);
+    load_b(kbeg);
+    store_tiles(0);
+  }
+  __syncthreads();
+
+  for (int kt = 0; kt < nkt; ++kt) {
+    const bool more = (kt + 1 < nkt);
+    if (more) {
+      load_a(kbeg + (kt + 1) * BK);
+      load_b(kbeg + (kt + 1) * BK);
+    }
+    const float *As = lds + (kt & 1) * (A_ELEMS + B_ELEMS);
+    const float *Bs = As + A_ELEMS;
+#pragma unroll
+    for (int g = 0; g < BK / 8; ++g) {
+      float af[TM][4], bf[TN][4];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        if (A_KMAJOR) {
+          const float4 t = *reinterpret_cast<const float4 *>(As + (wm0 + i * 32 + li) * PA + g * 8 + lh * 4);
+          af[i][0] = t.x; af[i][1] = t.y; af[i][2] = t.z; af[i][3] = t.w;
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) af[i][j] = As[(g * 8 + lh * 4 + j) * PA + wm0 + i * 32 + li];
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < TN; ++i) {
+        if (B_KMAJOR) {
+          const float4 t = *reinterpret_cast<const float4 *>(Bs + (wn0 + i * 32 + li) * PB + g * 8 + lh * 4);
+          bf[i][0] = t.x; bf[i][1] = t.y; bf[i][2] = t.z; bf[i][3] = t.w;
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) bf[i][j] = Bs[(g * 8 + lh * 4 + j) * PB + wn0 + i * 32 + li];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int q = 0; q < TN; ++q)
+            acc[i][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][j], bf[q][j], acc[i][q], 0, 0, 0);
+    }
+    if (more) store_tiles((kt + 1) & 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: accumulator register r of lane (li, lh) is C[(r&3) + 8*(r>>2) + 4*lh][li] ------
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int q = 0; q < TN; ++q)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const int col = n0 + wn0 + q * 32 + li;
+        if (row < p.M && col < p.N) epi_store<EPI>(p, row, col, acc[i][q][r], ks);
+      }
+}
+
+// ---- sum of split-K slabs + the element-wise step that follows the GEMM ------------------------
+template <int EPI, int VEC>
+__global__ __launch_bounds__(256) void slab_reduce_kernel(GemmParams p, const float *slabs, int ld_slab) {
+  const int c = (blockIdx.x * 256 + threadIdx.x) * VEC;
+  if (c >= p.N) return;
+  for (int r = blockIdx.y; r < p.M; r += gridDim.y) {
+    float acc[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
+    const float *src = slabs + (size_t)r * ld_slab + c;
+    for (int s = 0; s < p.splitk; ++s) {
+      if (VEC == 4) {
+        const float4 v = *reinterpret_cast<const float4 *>(src + (size_t)s * p.slab_stride);
+        acc[0] += v.x; acc[1] += v.y; acc[2] += v.z; acc[3] += v.w;
+      } else {
+        acc[0] += src[(size_t)s * p.slab_stride];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < VEC; ++i)
+      if (c + i < p.N) epi_store<EPI>(p, r, c + i, acc[i], 0);
+  }
+}
+
+// ---- host side ---------------------------------------------------------------------------------
+
+struct TileCfg {
+  int bm, bn;
+};
+const TileCfg kCfgs[] = {{64, 64}, {128, 64}, {64, 128}, {128, 128}};
+constexpr int kBK = 32;
+
+struct Plan {
+  int cfg;     // index into kCfgs
+  int splitk;
+  int k_per_split;
+};
+
+// Rough cycle model used to pick the tile and the split: MFMA time of the busiest CU, the
+// L2->LDS staging rate a CU sustains, a fixed prologue/epilogue cost per block, and the HBM
+// round trip of the partial slabs plus the extra launch when K is split.
+Plan make_plan(int M, int N, int K, int num_cu, bool allow_split) {
+  static int force_bm = -1, force_bn = -1, force_s = -1;
+  static bool env_read = false;
+  if (!env_read) {
+    env_read = true;
+    const char *e = getenv("KALDI_HIP_GEMM_FORCE");  // "BM,BN,S" for experiments
+    if (e) sscanf(e, "%d,%d,%d", &force_bm, &force_bn, &force_s);
+  }
+  Plan best = {0, 1, ((K + kBK - 1) / kBK) * kBK};
+  double best_cost = 1e300;
+  const int ncfg = (int)(sizeof(kCfgs) / sizeof(kCfgs[0]));
+  const int ktiles = (K + kBK - 1) / kBK;
+  for (int c = 0; c < ncfg; ++c) {
+    const int bm = kCfgs[c].bm, bn = kCfgs[c].bn;
+    if (force_bm > 0 && (bm != force_bm || bn != force_bn)) continue;
+    const int tm = (M + bm - 1) / bm, tn = (N + bn - 1) / bn;
+    for (int s = 1; s <= 16; s *= 2) {
+      if (s > 1 && !allow_split) break;
+      if (force_s > 0 && s != force_s) continue;
+      if (s > ktiles) break;
+      const int kt_per = (ktiles + s - 1) / s;
+      const int s_eff = (ktiles + kt_per - 1) / kt_per;
+      if (s_eff != s) continue;
+      const double blocks = (double)tm * tn * s;
+      const double rounds = ceil(blocks / num_cu);
+      const double kper = (double)kt_per * kBK;
+      const double mfma_cyc = (double)bm * bn * kper * 2.0 / 256.0;
+      const double load_cyc = (double)(bm + bn) * kper * 4.0 / 20.0;
+      double blk = (mfma_cyc > load_cyc ? mfma_cyc : load_cyc) + 3000.0;
+      double cost = rounds * blk;
+      if (s > 1) cost += 2.0 * s * (double)M * N * 4.0 / 4.0e12 * 2.4e9 + 5000.0;
+      if (cost < best_cost) {
+        best_cost = cost;
+        best.cfg = c;
+        best.splitk = s;
+        best.k_per_split = kt_per * kBK;
+      }
+    }
+  }
+  return best;
+}
+
+template <int BM, int BN, bool AK, bool BK_, int EPI>
+void launch_cfg(hipStream_t st, const GemmParams &p, bool vec) {
+  const int nblk = p.tiles_m * p.tiles_n * p.splitk;
+  if (vec)
+    hipLaunchKernelGGL((gemm_kernel<BM, BN, kBK, AK, BK_, EPI, true>), dim3(nblk), dim3(256), 0, st, p);
+  else
+    hipLaunchKernelGGL((gemm_kernel<BM, BN, kBK, AK, BK_, EPI, false>), dim3(nblk), dim3(256), 0, st, p);
+}
+
+template <bool AK, bool BK_, int EPI>
+void launch_tiles(hipStream_t st, const GemmParams &p, int cfg, bool vec) {
+  switch (cfg) {
+    case 0: launch_cfg<64, 64, AK, BK_, EPI>(st, p, vec); break;
+    case 1: launch_cfg<128, 64, AK, BK_, EPI>(st, p, vec); break;
+    case 2: launch_cfg<64, 128, AK, BK_, EPI>(st, p, vec); break;
+    default: launch_cfg<128, 128, AK, BK_, EPI>(st, p, vec); break;
+  }
+}
+
+template <int EPI>
+void launch_layout(hipStream_t st, const GemmParams &p, int cfg, bool vec, bool a_kmajor, bool b_kmajor) {
+  if (a_kmajor && b_kmajor) launch_tiles<true, true, EPI>(st, p, cfg, vec);
+  else if (a_kmajor && !b_kmajor) launch_tiles<true, false, EPI>(st, p, cfg, vec);
+  else if (!a_kmajor && b_kmajor) launch_tiles<false, true, EPI>(st, p, cfg, vec);
+  else launch_tiles<false, false, EPI>(st, p, cfg, vec);
+}
+
+template <int EPI>
+void launch_reduce(hipStream_t st, const GemmParams &p, const float *slabs, int ld_slab) {
+  const bool vec = (ld_slab % 4 == 0) && (p.slab_stride % 4 == 0);
+  const int per = vec ? 4 : 1;
+  int gx = (p.N + 256 * per - 1) / (256 * per);
+  int gy = p.M;
+  const int cap = 8192 / (gx > 0 ? gx : 1);
+  if (gy > cap) gy = cap < 1 ? 1 : cap;
+  if (vec)
+    hipLaunchKernelGGL((slab_reduce_kernel<EPI, 4>), dim3(gx, gy), dim3(256), 0, st, p, slabs, ld_slab);
+  else
+    hipLaunchKernelGGL((slab_reduce_kernel<EPI, 1>), dim3(gx, gy), dim3(256), 0, st, p, slabs, ld_slab);
+}
+
+// Runs op(A)*op(B) and the epilogue EPI.  `softmax` selects the row-softmax finish (always via
+// slabs, since a row spans many tiles).
+template <int EPI>
+int run_gemm(khStream_t s, bool a_kmajor, bool b_kmajor, GemmParams p, bool allow_split, bool softmax = false) {
+  hipStream_t st = kh::pick(s);
+  const bool vec = kh::aligned16(p.A) && kh::aligned16(p.B) && (p.lda % 4 == 0) && (p.ldb % 4 == 0);
+  Plan plan = make_plan(p.M, p.N, p.K, kh::ctx().num_cu > 0 ? kh::ctx().num_cu : 256, allow_split || softmax);
+  const int bm = kCfgs[plan.cfg].bm, bn = kCfgs[plan.cfg].bn;
+  p.tiles_m = (p.M + bm - 1) / bm;
+  p.tiles_n = (p.N + bn - 1) / bn;
+  p.splitk = plan.splitk;
+  p.k_per_split = plan.k_per_split;
+  if (p.splitk == 1 && !softmax) {
+    launch_layout<EPI>(st, p, plan.cfg, vec, a_kmajor, b_kmajor);
+    return kh::launch_status();
+  }
+  // partial slabs in the workspace, then the fused finish
+  const int ld_slab = (p.N + 3) & ~3;
+  const size_t slab_stride = (size_t)p.M * ld_slab;
+  void *ws;
+  int rc = kh::ensure_workspace(slab_stride * p.splitk * sizeof(float), &ws);
+  if (rc != KH_OK) return rc;
+  GemmParams ps = p;
+  ps.C = (float *)ws;
+  ps.ldc = ld_slab;
+  ps.slab_stride = slab_stride;
+  launch_layout<EPI_SLAB>(st, ps, plan.cfg, vec, a_kmajor, b_kmajor);
+  rc = kh::launch_status();
+  if (rc != KH_OK) return rc;
+  p.slab_stride = slab_stride;
+  if (softmax)
+    return kh::softmax_slabs_launch(st, p.C, p.ldc, (const float *)ws, ld_slab, p.splitk, slab_stride, p.bias, p.M,
+                                    p.N);
+  launch_reduce<EPI>(st, p, (const float *)ws, ld_slab);
+  return kh::launch_status();
+}
+
+GemmParams base_params(int M, int N, int K, const float *A, int lda, const float *B, int ldb, float *C, int ldc) {
+  GemmParams p;
+  memset(&p, 0, sizeof(p));
+  p.A = A; p.B = B; p.lda = lda; p.ldb = ldb;
+  p.M = M; p.N = N; p.K = K;
+  p.C = C; p.ldc = ldc;
+  p.alpha = 1.f; p.beta = 0.f;
+  return p;
+}
+
+// vectors of the bias update: bcorr = g*colsum(e) + mom*bcorr ; b -= lr*bcorr
+__global__ __launch_bounds__(1024) void bias_update_kernel(const float *e, int lde, int N, int O, float g, float mom,
+                                                           float lr, float *bias, float *bcorr) {
+  __shared__ float part[16][64];
+  const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
+  float acc = 0.f;
+  if (c < O)
+    for (int r = grp; r < N; r += 16) acc += e[(size_t)r * lde + c];
+  part[grp][lane] = acc;
+  __syncthreads();
+  if (grp == 0 && c < O) {
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) t += part[i][lane];
+    float bc = g * t;
+    if (mom != 0.f) bc += mom * bcorr[c];
+    if (bcorr) bcorr[c] = bc;
+    bias[c] = -lr * bc + bias[c];
+  }
+}
+
+// RBM bias statistics: d = mom*d - g*colsum(neg) + g*colsum(pos) ; b += d
+__global__ __launch_bounds__(1024) void rbm_bias_kernel(const float *pos, int ldp, const float *neg, int ldn, int N,
+                                                        int D, float g, float mom, float *bias, float *dbias) {
+  __shared__ float pp[16][64];
+  __shared__ float pn[16][64];
+  const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
+  float ap = 0.f, an = 0.f;
+  if (c < D)
+    for (int r = grp; r < N; r += 16) {
+      ap += pos[(size_t)r * ldp + c];
+      an += neg[(size_t)r * ldn + c];
+    }
+  pp[grp][lane] = ap;
+  pn[grp][lane] = an;
+  __syncthreads();
+  if (grp == 0 && c < D) {
+    float tp = 0.f, tn = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      tp += pp[i][lane];
+      tn += pn[i][lane];
+    }
+    float d = -g * tn + mom * dbias[c];
+    d = g * tp + d;
+    dbias[c] = d;
+    bias[c] = d + bias[c];
+  }
+}
+
+}  // namespace
+
+KH_EXPORT int hipF_gemm(khStream_t s, int transA, int transB, int32_t M, int32_t N, int32_t K, float alpha,
+                        const float *A, int32_t lda, const float *B, int32_t ldb, float beta, float *C, int32_t ldc) {
+  KH_CHECK_INIT();
+  KH_REQUIRE((transA == KH_NO_TRANS || transA == KH_TRANS) && (transB == KH_NO_TRANS || transB == KH_TRANS));
+  KH_REQUIRE(M >= 0 && N >= 0 && K >= 0);
+  if (M == 0 || N == 0) return KH_OK;
+  KH_REQUIRE(C != nullptr && ldc >= N);
+  const bool a_kmajor = (transA == KH_NO_TRANS), b_kmajor = (transB == KH_TRANS);
+  if (K > 0) {
+    KH_REQUIRE(A != nullptr && B != nullptr);
+    KH_REQUIRE(lda >= (a_kmajor ? K : M) && ldb >= (b_kmajor ? K : N));
+  }
+  GemmParams p = base_params(M, N, K, A, lda, B, ldb, C, ldc);
+  p.alpha = alpha;
+  p.beta = beta;
+  return run_gemm<EPI_AXPBY>(s, a_kmajor, b_kmajor, p, /*allow_split=*/true);
+}
+
+KH_EXPORT int hipF_affine_forward(khStream_t s, int act, int trans_w, int32_t N, int32_t O, int32_t I,
+                                  const float *in, int32_t ldin, const float *W, int32_t ldw, const float *bias,
+                                  float *out, int32_t ldout) {
+  KH_CHECK_INIT();
+  KH_REQUIRE(act == KH_ACT_NONE || act == KH_ACT_SIGMOID || act == KH_ACT_SOFTMAX);
+  KH_REQUIRE(trans_w == KH_TRANS || trans_w == KH_NO_TRANS);
+  KH_REQUIRE(N >= 0 && O > 0 && I > 0);
+  if (N == 0) return KH_OK;
+  KH_REQUIRE(in && W && bias && out && ldin >= I && ldout >= O);
+  const bool b_kmajor = (trans_w == KH_TRANS);  // W is O x I (k contiguous) or I x O
+  KH_REQUIRE(ldw >= (b_kmajor ? I : O));
+  GemmParams p = base_params(N, O, I, in, ldin, W, ldw, out, ldout);
+  p.bias = bias;
+  p.act = act;
+  return run_gemm<EPI_BIAS_ACT>(s, true, b_kmajor, p, true, act == KH_ACT_SOFTMAX);
+}
+
+KH_EXPORT int hipF_affine_backward(khStream_t s, int32_t N, int32_t O, int32_t I, const float *e, int32_t lde,
+                                   const float *W, int32_t ldw, const float *y, int32_t ldy, float *eout,
+                                   int32_t ldeout) {
+  KH_CHECK_INIT();
+  KH_REQUIRE(N >= 0 && O > 0 && I > 0);
+  if (N == 0) return KH_OK;
+  KH_REQUIRE(e && W && eout && lde >= O && ldw >= I && ldeout >= I && (y == nullptr || ldy >= I));
+  GemmParams p = base_params(N, I, O, e, lde, W, ldw, eout, ldeout);
+  if (y) {
+    p.y = y;
+    p.ldy = ldy;
+    return run_gemm<EPI_DSIG>(s, true, false, p, true);
+  }
+  return run_gemm<EPI_AXPBY>(s, true, false, p, true);
+}
+
+KH_EXPORT int hipF_affine_update(khStream_t s, int32_t N, int32_t O, int32_t I, const float *e, int32_t lde,
+                                 const float *in, int32_t ldin, float gscale, float momentum, float lr, float l2,
+                                 float *W, int32_t ldw, float *corr, int32_t ldcorr, float *bias, float *bcorr) {
+  KH_CHECK_INIT();
+  KH_REQUIRE(N > 0 && O > 0 && I > 0);
+  KH_REQUIRE(e && in && W && bias && lde >= O && ldin >= I && ldw >= I);
+  KH_REQUIRE(momentum == 0.f || (corr != nullptr && bcorr != nullptr));
+  KH_REQUIRE(corr == nullptr || ldcorr >= I);
+  // weights: corr(OxI) = g * e^T(OxN) * in(NxI) + mom*corr, W updated in the same epilogue
+  GemmParams p = base_params(O, I, N, e, lde, in, ldin, corr, ldcorr);
+  p.alpha = gscale;
+  p.mom = momentum;
+  p.lr = lr;
+  p.l2 = l2;
+  p.W = W;
+  p.ldw = ldw;
+  int rc = run_gemm<EPI_UPDATE>(s, false, false, p, /*allow_split=*/false);
+  if (rc != KH_OK) return rc;
+  hipLaunchKernelGGL(bias_update_kernel, dim3((O + 63) / 64), dim3(1024), 0, kh::pick(s), e, lde, N, O, gscale,
+                     momentum, lr, bias, bcorr);
+  return kh::launch_status();
+}
+
+KH_EXPORT int hipF_rbm_update(khStream_t s, int32_t N, int32_t H, int32_t V, const float *pos_vis, int32_t ldpv,
+                              const float *pos_hid, int32_t ldph, const float *neg_vis, int32_t ldnv,
+                              const float *neg_hid, int32_t ldnh, float lr, float momentum, float l2, float *W,
+                              int32_t ldw, float *dW, int32_t lddw, float *vis_bias, float *dvis_bias,
+                              float *hid_bias, float *dhid_bias) {
+  KH_CHECK_INIT();
+  KH_REQUIRE(N > 0 && H > 0 && V > 0);
+  KH_REQUIRE(pos_vis && pos_hid && neg_vis && neg_hid && W && dW && vis_bias && dvis_bias && hid_bias && dhid_bias);
+  KH_REQUIRE(ldpv >= V && ldnv >= V && ldph >= H && ldnh >= H && ldw >= V && lddw >= V);
+  const float g = lr / (float)N;
+  // dW = -g * neg_hid^T neg_vis + mom * dW
+  GemmParams p1 = base_params(H, V, N, neg_hid, ldnh, neg_vis, ldnv, dW, lddw);
+  p1.alpha = -g;
+  p1.beta = momentum;
+  int rc = run_gemm<EPI_AXPBY>(s, false, false, p1, false);
+  if (rc != KH_OK) return rc;
+  // dW = +g * pos_hid^T pos_vis + dW - lr*l2*W ; W += dW
+  GemmParams p2 = base_params(H, V, N, pos_hid, ldph, pos_vis, ldpv, dW, lddw);
+  p2.alpha = g;
+  p2.l2 = lr * l2;
+  p2.W = W;
+  p2.ldw = ldw;
+  rc = run_gemm<EPI_RBM>(s, false, false, p2, false);
+  if (rc != KH_OK) return rc;
+  hipStream_t st = kh::pick(s);
+  hipLaunchKernelGGL(rbm_bias_kernel, dim3((V + 63) / 64), dim3(1024), 0, st, pos_vis, ldpv, neg_vis, ldnv, N, V, g,
+                     momentum, vis_bias, dvis_bias);
+  hipLaunchKernelGGL(rbm_bias_kernel, dim3((H + 63) / 64), dim3(1024), 0, st, pos_hid, ldph, neg_hid, ldnh, N, H, g,
+                     momentum, hid_bias, dhid_bias);
+  return kh::launch_status();
+}

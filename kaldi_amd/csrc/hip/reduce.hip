@@ -1,0 +1,383 @@
+// Row / column reductions of the hot path: bias-gradient column sums, row sums, row softmax,
+// row argmax, cross-entropy and MSE evaluation.  All HBM-bound: one pass over the matrix,
+// 64-lane wavefront reductions (DPP/shuffle), LDS only to combine the waves of a block.
+#include "common.h"
+
+namespace {
+
+// ---- vec[c] = alpha * sum_r mat[r,c] + beta * vec[c] ---------------------------------------
+// Block = 64 columns x 16 row groups; lane -> column keeps every wave load a contiguous 256 B.
+// The per-group partial sums are combined in a fixed order, so results are reproducible.
+__global__ __launch_bounds__(1024) void col_sums_kernel(float alpha, const float *mat, MatrixDim d, float beta,
+                                                        float *vec) {
+  __shared__ float part[16][64];
+  const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
+  float acc = 0.f;
+  if (c < d.cols) {
+    const float *p = mat + c;
+    int r = g;
+    // four independent loads in flight per lane
+    for (; r + 48 < d.rows; r += 64) {
+      float a0 = p[(size_t)r * d.stride], a1 = p[(size_t)(r + 16) * d.stride];
+      float a2 = p[(size_t)(r + 32) * d.stride], a3 = p[(size_t)(r + 48) * d.stride];
+      acc += (a0 + a1) + (a2 + a3);
+    }
+    for (; r < d.rows; r += 16) acc += p[(size_t)r * d.stride];
+  }
+  part[g][lane] = acc;
+  __syncthreads();
+  if (g == 0 && c < d.cols) {
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) t += part[i][lane];
+    vec[c] = (beta == 0.f) ? alpha * t : alpha * t + beta * vec[c];
+  }
+}
+
+// ---- vec[r] = alpha * sum_c mat[r,c] + beta * vec[r] ---------------------------------------
+__global__ __launch_bounds__(256) void row_sums_kernel(float alpha, const float *mat, MatrixDim d, float beta,
+                                                       float *vec) {
+  __shared__ float red[16];
+  const int r = blockIdx.x;
+  const float *p = mat + (size_t)r * d.stride;
+  float acc = 0.f;
+  for (int c = threadIdx.x; c < d.cols; c += 256) acc += p[c];
+  const float t = kh::block_sum(acc, red);
+  if (threadIdx.x == 0) vec[r] = (beta == 0.f) ? alpha * t : alpha * t + beta * vec[r];
+}
+
+// ---- row softmax ---------------------------------------------------------------------------
+// One block per row.  The row is staged in LDS while its maximum is found, exponentiated in
+// place while the sum is formed, then scaled on the way out: x is read once, y written once.
+// Rows longer than the LDS staging buffer re-read x from L2 instead.
+constexpr int kSoftmaxThreads = 512;
+constexpr int kSoftmaxLdsFloats = 12288;  // 48 KiB: up to 3 blocks per CU
+
+// x may be given as `nslab` partial slabs (split-K GEMM output) plus a per-column bias; the
+// row value is then bias[c] + slab0[c] + slab1[c] + ... summed in slab order.
+template <bool STAGED>
+__global__ __launch_bounds__(kSoftmaxThreads) void softmax_kernel(float *y, int ldy, const float *x, int ldx,
+                                                                  int nslab, size_t slab_stride, const float *bias,
+                                                                  int cols) {
+  __shared__ float row[STAGED ? kSoftmaxLdsFloats : 1];
+  __shared__ float red[16];
+  const int r = blockIdx.x;
+  const float *px = x + (size_t)r * ldx;
+  float *py = y + (size_t)r * ldy;
+  const int t = threadIdx.x;
+
+  auto value = [&](int c) {
+    float v = px[c];
+    for (int s = 1; s < nslab; ++s) v += px[(size_t)s * slab_stride + c];
+    if (bias) v += bias[c];
+    return v;
+  };
+
+  float mx = -INFINITY;
+  for (int c = t; c < cols; c += kSoftmaxThreads) {
+    const float v = value(c);
+    if (STAGED) row[c] = v; else py[c] = v;
+    mx = fmaxf(mx, v);
+  }
+  mx = kh::block_max(mx, red);
+
+  float sum = 0.f;
+  for (int c = t; c < cols; c += kSoftmaxThreads) {
+    const float e = expf((STAGED ? row[c] : py[c]) - mx);
+    if (STAGED) row[c] = e; else py[c] = e;
+    sum += e;
+  }
+  sum = kh::block_sum(sum, red);
+  const float inv = 1.0f / sum;
+  for (int c = t; c < cols; c += kSoftmaxThreads) py[c] = (STAGED ? row[c] : py[c]) * inv;
+}
+
+__global__ __launch_bounds__(256) void softmax_part_kernel(const float *X, const int32_t *ids, float *Y,
+                                                           MatrixDim d) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= d.cols) return;
+  for (int r = blockIdx.y; r < d.rows; r += gridDim.y) {
+    const size_t base = (size_t)r * d.stride;
+    Y[base + c] = expf(X[base + c] - X[base + ids[r]]);
+  }
+}
+
+// ---- row argmax ----------------------------------------------------------------------------
+struct MaxId {
+  float v;
+  int32_t i;
+};
+// larger value wins; equal values keep the lower column index (first maximum of the row)
+__device__ __forceinline__ MaxId better(MaxId a, MaxId b) {
+  if (b.v > a.v || (b.v == a.v && b.i >= 0 && (a.i < 0 || b.i < a.i))) return b;
+  return a;
+}
+__device__ __forceinline__ MaxId wave_best(MaxId m) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    MaxId other;
+    other.v = __shfl_xor(m.v, o, 64);
+    other.i = __shfl_xor(m.i, o, 64);
+    m = better(m, other);
+  }
+  return m;
+}
+// Row argmax of p[0..cols): start value -1e21 / id -1 and a strict '>' test, like the
+// reference's CPU loop (cu-math-inl.h:339-348).  Result valid in every thread.
+__device__ __forceinline__ MaxId block_row_argmax(const float *p, int cols, float *sv, int32_t *si) {
+  MaxId m;
+  m.v = -1e21f;
+  m.i = -1;
+  for (int c = threadIdx.x; c < cols; c += blockDim.x) {
+    const float v = p[c];
+    if (v > m.v) {  // ascending c per thread: the first maximum is kept
+      m.v = v;
+      m.i = c;
+    }
+  }
+  m = wave_best(m);
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  __syncthreads();
+  if (lane == 0) {
+    sv[wid] = m.v;
+    si[wid] = m.i;
+  }
+  __syncthreads();
+  MaxId b;
+  b.v = sv[0];
+  b.i = si[0];
+  for (int w = 1; w < nw; ++w) {
+    MaxId o;
+    o.v = sv[w];
+    o.i = si[w];
+    b = better(b, o);
+  }
+  return b;
+}
+
+__global__ __launch_bounds__(256) void find_row_max_id_kernel(const float *mat, float *vec_val, int32_t *vec_id,
+                                                              MatrixDim d) {
+  __shared__ float sv[16];
+  __shared__ int32_t si[16];
+  const int r = blockIdx.x;
+  MaxId b = block_row_argmax(mat + (size_t)r * d.stride, d.cols, sv, si);
+  if (threadIdx.x == 0) {
+    vec_id[r] = b.i;
+    if (vec_val) vec_val[r] = b.v;
+  }
+}
+
+__global__ void diff_xent_kernel(const int32_t *tgt, float *mat, float *log_post, MatrixDim d) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= d.rows) return;
+  const int t = tgt[r];
+  if (t < 0 || t >= d.cols) {  // label outside the output layer: nothing to subtract from
+    log_post[r] = logf(1e-20f);
+    return;
+  }
+  const size_t idx = (size_t)r * d.stride + t;
+  float v = mat[idx];
+  const float fl = (v < 1e-20f) ? 1e-20f : v;
+  log_post[r] = logf(fl);
+  mat[idx] = v - 1.0f;
+}
+
+// ---- fused Xent::EvalVec -------------------------------------------------------------------
+// pass 1: one block per row: argmax, log posterior of the target, diff = post - onehot
+__global__ __launch_bounds__(256) void xent_rows_kernel(const float *post, const int32_t *tgt, float *diff,
+                                                        float *log_post, int32_t *max_id, MatrixDim d) {
+  __shared__ float sv[16];
+  __shared__ int32_t si[16];
+  const int r = blockIdx.x;
+  const float *p = post + (size_t)r * d.stride;
+  float *q = diff + (size_t)r * d.stride;
+  const int t = tgt[r];
+  const bool t_ok = (t >= 0 && t < d.cols);  // a label outside the output layer counts as posterior 0
+  // argmax on the unmodified posteriors (diff may alias post, so finish reading first)
+  MaxId b = block_row_argmax(p, d.cols, sv, si);
+  const float pt = t_ok ? p[t] : 0.0f;
+  __syncthreads();
+  if (q != p) {
+    for (int c = threadIdx.x; c < d.cols; c += 256) q[c] = (c == t) ? p[c] - 1.0f : p[c];
+  } else if (threadIdx.x == 0 && t_ok) {
+    q[t] = pt - 1.0f;
+  }
+  if (threadIdx.x == 0) {
+    max_id[r] = b.i;
+    log_post[r] = logf(pt < 1e-20f ? 1e-20f : pt);
+  }
+}
+// pass 2: one block: counters and loss in a fixed order
+__global__ __launch_bounds__(256) void xent_accum_kernel(const int32_t *tgt, const float *log_post,
+                                                         const int32_t *max_id, long long *counters, double *loss,
+                                                         int rows) {
+  __shared__ double sd[256];
+  __shared__ int sc[256];
+  double acc = 0.0;
+  int correct = 0;
+  for (int r = threadIdx.x; r < rows; r += 256) {
+    acc += (double)log_post[r];
+    correct += (max_id[r] == tgt[r]) ? 1 : 0;
+  }
+  sd[threadIdx.x] = acc;
+  sc[threadIdx.x] = correct;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) {
+      sd[threadIdx.x] += sd[threadIdx.x + o];
+      sc[threadIdx.x] += sc[threadIdx.x + o];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    counters[0] += sc[0];
+    counters[1] += rows;
+    loss[0] -= sd[0];
+  }
+}
+
+// ---- fused Mse / MseProgress Eval ------------------------------------------------------------
+__global__ __launch_bounds__(256) void mse_rows_kernel(const float *a, const float *b, float *diff, float *row_sq,
+                                                       MatrixDim d) {
+  __shared__ float red[16];
+  const int r = blockIdx.x;
+  const size_t base = (size_t)r * d.stride;
+  float acc = 0.f;
+  for (int c = threadIdx.x; c < d.cols; c += 256) {
+    const float df = a[base + c] - b[base + c];
+    if (diff) diff[base + c] = df;
+    acc += df * df;
+  }
+  const float t = kh::block_sum(acc, red);
+  if (threadIdx.x == 0) row_sq[r] = t;
+}
+__global__ __launch_bounds__(256) void mse_accum_kernel(const float *row_sq, double *loss, int rows) {
+  __shared__ double sd[256];
+  double acc = 0.0;
+  for (int r = threadIdx.x; r < rows; r += 256) acc += (double)row_sq[r];
+  sd[threadIdx.x] = acc;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) sd[threadIdx.x] += sd[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) loss[0] += 0.5 * sd[0];
+}
+
+}  // namespace
+
+namespace kh {
+int softmax_slabs_launch(hipStream_t st, float *y, int ldy, const float *x, int ldx, int nslab, size_t slab_stride,
+                         const float *bias, int rows, int cols) {
+  if (cols <= kSoftmaxLdsFloats)
+    hipLaunchKernelGGL((softmax_kernel<true>), dim3(rows), dim3(kSoftmaxThreads), 0, st, y, ldy, x, ldx, nslab,
+                       slab_stride, bias, cols);
+  else
+    hipLaunchKernelGGL((softmax_kernel<false>), dim3(rows), dim3(kSoftmaxThreads), 0, st, y, ldy, x, ldx, nslab,
+                       slab_stride, bias, cols);
+  return kh::launch_status();
+}
+}  // namespace kh
+
+KH_EXPORT int hipF_add_row_sum_mat(khStream_t s, float alpha, const float *mat, MatrixDim d, float beta,
+                                   float *vec) {
+  KH_CHECK_INIT();
+  KH_REQUIRE(kh::dim_ok(d));
+  if (d.cols == 0) return KH_OK;
+  KH_REQUIRE(vec != nullptr && (d.rows == 0 || mat != nullptr));
+  hipLaunchKernelGGL(col_sums_kernel, dim3((d.cols + 63) / 64), dim3(1024), 0, kh::pick(s), alpha, mat, d, beta,
+                     vec);
+  return kh::launch_status();
+}
+
+KH_EXPORT int hipF_add_col_sum_mat(khStream_t s, float alpha, const float *mat, MatrixDim d, float beta,
+                                   float *vec) {
+  KH_CHECK_INIT();
+  KH_REQUIRE(kh::dim_ok(d));
+  if (d.rows == 0) return KH_OK;
+  KH_REQUIRE(vec != nullptr && (d.cols == 0 || mat != nullptr));
+  hipLaunchKernelGGL(row_sums_kernel, dim3(d.rows), dim3(256), 0, kh::pick(s), alpha, mat, d, beta, vec);
+  return kh::launch_status();
+}
+
+KH_EXPORT int hipF_softmax(khStream_t s, float *y, const float *x, MatrixDim d) {
+  KH_CHECK_INIT();
+  KH_REQUIRE(kh::dim_ok(d));
+  if (d.rows == 0 || d.cols == 0) return KH_OK;
+  KH_REQUIRE(y != nullptr && x != nullptr);
+  return kh::softmax_slabs_launch(kh::pick(s), y, d.stride, x, d.stride, 1, 0, nullptr, d.rows, d.cols);
+}
+
+KH_EXPORT int hipF_softmax_part(khStream_t s, const float *X, const int32_t *vec_ids, float *Y, MatrixDim d) {
+  KH_CHECK_INIT();
+  KH_REQUIRE(kh::dim_ok(d));
+  if (d.rows == 0 || d.cols == 0) return KH_OK;
+  KH_REQUIRE(X && vec_ids && Y);
+  int gx = (d.cols + 255) / 256, gy = d.rows;
+  int cap = 8192 / gx;
+  if (gy > cap) gy = cap < 1 ? 1 : cap;
+  hipLaunchKernelGGL(softmax_part_kernel, dim3(gx, gy), dim3(256), 0, kh::pick(s), X, vec_ids, Y, d);
+  return kh::launch_status();
+}
+
+KH_EXPORT int hipF_find_row_max_id(khStream_t s, const float *mat, float *vec_val, int32_t *vec_id, MatrixDim d) {
+  KH_CHECK_INIT();
+  KH_REQUIRE(kh::dim_ok(d));
+  if (d.rows == 0) return KH_OK;
+  KH_REQUIRE(vec_id != nullptr && (d.cols == 0 || mat != nullptr));
+  hipLaunchKernelGGL(find_row_max_id_kernel, dim3(d.rows), dim3(256), 0, kh::pick(s), mat, vec_val, vec_id, d);
+  return kh::launch_status();
+}
+
+KH_EXPORT int hipF_diff_xent(khStream_t s, const int32_t *vec_tgt, float *mat_net_out, float *vec_log_post,
+                             MatrixDim d) {
+  KH_CHECK_INIT();
+  KH_REQUIRE(kh::dim_ok(d));
+  if (d.rows == 0) return KH_OK;
+  KH_REQUIRE(vec_tgt && mat_net_out && vec_log_post && d.cols > 0);
+  hipLaunchKernelGGL(diff_xent_kernel, dim3((d.rows + 127) / 128), dim3(128), 0, kh::pick(s), vec_tgt, mat_net_out,
+                     vec_log_post, d);
+  return kh::launch_status();
+}
+
+KH_EXPORT int hipF_xent_eval(khStream_t s, const float *post, const int32_t *tgt, float *diff, float *log_post,
+                             int32_t *max_id, long long *counters, double *loss, MatrixDim d) {
+  KH_CHECK_INIT();
+  KH_REQUIRE(kh::dim_ok(d));
+  if (d.rows == 0) return KH_OK;
+  KH_REQUIRE(post && tgt && diff && counters && loss && d.cols > 0);
+  // per-row results go to the caller's vectors or to library scratch
+  float *lp = log_post;
+  int32_t *mi = max_id;
+  if (!lp || !mi) {
+    void *ws;
+    int st = kh::ensure_workspace((size_t)d.rows * 8, &ws);
+    if (st != KH_OK) return st;
+    if (!lp) lp = (float *)ws;
+    if (!mi) mi = (int32_t *)((char *)ws + (size_t)d.rows * 4);
+  }
+  hipStream_t st = kh::pick(s);
+  hipLaunchKernelGGL(xent_rows_kernel, dim3(d.rows), dim3(256), 0, st, post, tgt, diff, lp, mi, d);
+  hipLaunchKernelGGL(xent_accum_kernel, dim3(1), dim3(256), 0, st, tgt, lp, mi, counters, loss, d.rows);
+  return kh::launch_status();
+}
+
+KH_EXPORT int hipF_mse_eval(khStream_t s, const float *a, const float *b, float *diff, float *row_sq, double *loss,
+                            MatrixDim d) {
+  KH_CHECK_INIT();
+  KH_REQUIRE(kh::dim_ok(d));
+  if (d.rows == 0) return KH_OK;
+  KH_REQUIRE(a && b && loss);
+  float *rs = row_sq;
+  if (!rs) {
+    void *ws;
+    int st = kh::ensure_workspace((size_t)d.rows * 4, &ws);
+    if (st != KH_OK) return st;
+    rs = (float *)ws;
+  }
+  hipStream_t st = kh::pick(s);
+  hipLaunchKernelGGL(mse_rows_kernel, dim3(d.rows), dim3(256), 0, st, a, b, diff, rs, d);
+  hipLaunchKernelGGL(mse_accum_kernel, dim3(1), dim3(256), 0, st, rs, loss, d.rows);
+  return kh::launch_status();
+}

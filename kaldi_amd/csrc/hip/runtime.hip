@@ -1,0 +1,249 @@
+// Device selection, memory and copies: what the reference took from the CUDA runtime and
+// cu-device.cc (src/cudamatrix/cu-device.cc:56-210, cu-matrix-inl.h:96-310).
+#include <string.h>
+
+#include "common.h"
+
+namespace kh {
+
+Context &ctx() {
+  static Context c;
+  return c;
+}
+
+int ensure_workspace(size_t bytes, void **ptr) {
+  Context &c = ctx();
+  if (bytes > c.workspace_bytes) {
+    // Allocation churn is what this avoids: round up generously, reallocate rarely.
+    size_t want = bytes + bytes / 4;
+    want = (want + ((size_t)1 << 20) - 1) & ~(((size_t)1 << 20) - 1);
+    KH_HIP(hipDeviceSynchronize());
+    if (c.workspace) KH_HIP(hipFree(c.workspace));
+    c.workspace = nullptr;
+    c.workspace_bytes = 0;
+    KH_HIP(hipMalloc(&c.workspace, want));
+    c.workspace_bytes = want;
+  }
+  *ptr = c.workspace;
+  return KH_OK;
+}
+
+}  // namespace kh
+
+using kh::ctx;
+
+KH_EXPORT int hipK_device_count(int *count) {
+  KH_REQUIRE(count != nullptr);
+  KH_HIP(hipGetDeviceCount(count));
+  return KH_OK;
+}
+
+KH_EXPORT int hipK_init(int device_id) {
+  kh::Context &c = ctx();
+  if (c.initialised && (device_id < 0 || device_id == c.device)) return KH_OK;
+  if (c.initialised) {
+    int st = hipK_shutdown();
+    if (st != KH_OK) return st;
+  }
+  int n = 0;
+  KH_HIP(hipGetDeviceCount(&n));
+  if (n <= 0) return (int)hipErrorNoDevice;
+  int chosen = device_id;
+  if (device_id < 0) {
+    // the GPU with the most free memory, like CuDevice's automatic selection
+    size_t best_free = 0;
+    chosen = 0;
+    for (int i = 0; i < n; ++i) {
+      size_t f = 0, t = 0;
+      if (hipSetDevice(i) != hipSuccess) continue;
+      if (hipMemGetInfo(&f, &t) != hipSuccess) continue;
+      if (f > best_free) {
+        best_free = f;
+        chosen = i;
+      }
+    }
+  } else if (device_id >= n) {
+    snprintf(c.last_msg, sizeof(c.last_msg), "hipK_init: device %d requested, %d visible", device_id, n);
+    return KH_ERR_INVALID_ARG;
+  }
+  KH_HIP(hipSetDevice(chosen));
+  hipDeviceProp_t prop;
+  KH_HIP(hipGetDeviceProperties(&prop, chosen));
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+    snprintf(c.last_msg, sizeof(c.last_msg), "hipK_init: device %d is %s; this library is built for gfx950 only",
+             chosen, prop.gcnArchName);
+    return KH_ERR_INVALID_ARG;
+  }
+  KH_HIP(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+  c.device = chosen;
+  c.num_cu = prop.multiProcessorCount;
+  c.initialised = true;
+  return KH_OK;
+}
+
+KH_EXPORT int hipK_shutdown(void) {
+  kh::Context &c = ctx();
+  if (!c.initialised) return KH_OK;
+  KH_HIP(hipDeviceSynchronize());
+  if (c.workspace) KH_HIP(hipFree(c.workspace));
+  c.workspace = nullptr;
+  c.workspace_bytes = 0;
+  if (c.stream) KH_HIP(hipStreamDestroy(c.stream));
+  c.stream = nullptr;
+  c.initialised = false;
+  c.device = -1;
+  return KH_OK;
+}
+
+KH_EXPORT int hipK_active_device(int *device_id) {
+  KH_REQUIRE(device_id != nullptr);
+  *device_id = ctx().initialised ? ctx().device : -1;
+  return KH_OK;
+}
+
+KH_EXPORT int hipK_mem_info(size_t *free_bytes, size_t *total_bytes) {
+  KH_CHECK_INIT();
+  KH_REQUIRE(free_bytes && total_bytes);
+  KH_HIP(hipMemGetInfo(free_bytes, total_bytes));
+  return KH_OK;
+}
+
+KH_EXPORT int hipK_default_stream(khStream_t *stream) {
+  KH_CHECK_INIT();
+  KH_REQUIRE(stream != nullptr);
+  *stream = (khStream_t)ctx().stream;
+  return KH_OK;
+}
+
+KH_EXPORT int hipK_stream_create(khStream_t *stream) {
+  KH_CHECK_INIT();
+  KH_REQUIRE(stream != nullptr);
+  hipStream_t s;
+  KH_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+  *stream = (khStream_t)s;
+  return KH_OK;
+}
+
+KH_EXPORT int hipK_stream_destroy(khStream_t stream) {
+  KH_REQUIRE(stream != nullptr);
+  KH_HIP(hipStreamDestroy((hipStream_t)stream));
+  return KH_OK;
+}
+
+KH_EXPORT int hipK_stream_synchronize(khStream_t stream) {
+  KH_CHECK_INIT();
+  KH_HIP(hipStreamSynchronize(kh::pick(stream)));
+  return KH_OK;
+}
+
+KH_EXPORT int hipK_device_synchronize(void) {
+  KH_CHECK_INIT();
+  KH_HIP(hipDeviceSynchronize());
+  return KH_OK;
+}
+
+KH_EXPORT const char *hipK_error_string(int status) {
+  switch (status) {
+    case KH_OK: return "success";
+    case KH_ERR_INVALID_ARG: return ctx().last_msg[0] ? ctx().last_msg : "invalid argument";
+    case KH_ERR_NOT_INITIALISED: return "library not initialised";
+    case KH_ERR_COMM: return ctx().last_msg[0] ? ctx().last_msg : "RCCL error";
+    case KH_ERR_TOO_LARGE: return ctx().last_msg[0] ? ctx().last_msg : "size beyond the supported maximum";
+    default: return hipGetErrorString((hipError_t)status);
+  }
+}
+
+KH_EXPORT int hipK_device_props(int *num_cu, int *wave_size, char *arch_name, size_t arch_name_len) {
+  KH_CHECK_INIT();
+  hipDeviceProp_t prop;
+  KH_HIP(hipGetDeviceProperties(&prop, ctx().device));
+  if (num_cu) *num_cu = prop.multiProcessorCount;
+  if (wave_size) *wave_size = prop.warpSize;
+  if (arch_name && arch_name_len) {
+    strncpy(arch_name, prop.gcnArchName, arch_name_len - 1);
+    arch_name[arch_name_len - 1] = 0;
+  }
+  return KH_OK;
+}
+
+KH_EXPORT int hipK_malloc_pitch(void **ptr, int32_t *stride_elems, int32_t rows, int32_t cols, size_t elem_size) {
+  KH_CHECK_INIT();
+  KH_REQUIRE(ptr && stride_elems && rows >= 0 && cols >= 0 && (elem_size == 4 || elem_size == 8));
+  // Rows start on 256-byte boundaries: whole rows are then made of full 128-byte lines and every
+  // row base is 16-byte aligned for dwordx4 accesses.
+  size_t pitch = ((size_t)cols * elem_size + 255) & ~(size_t)255;
+  *stride_elems = (int32_t)(pitch / elem_size);
+  *ptr = nullptr;
+  if (rows == 0 || cols == 0) return KH_OK;
+  KH_HIP(hipMalloc(ptr, pitch * (size_t)rows));
+  return KH_OK;
+}
+
+KH_EXPORT int hipK_malloc(void **ptr, size_t bytes) {
+  KH_CHECK_INIT();
+  KH_REQUIRE(ptr != nullptr);
+  *ptr = nullptr;
+  if (bytes == 0) return KH_OK;
+  KH_HIP(hipMalloc(ptr, bytes));
+  return KH_OK;
+}
+
+KH_EXPORT int hipK_free(void *ptr) {
+  if (!ptr) return KH_OK;
+  KH_HIP(hipFree(ptr));
+  return KH_OK;
+}
+
+KH_EXPORT int hipK_malloc_host(void **ptr, size_t bytes) {
+  KH_CHECK_INIT();
+  KH_REQUIRE(ptr != nullptr);
+  *ptr = nullptr;
+  if (bytes == 0) return KH_OK;
+  KH_HIP(hipHostMalloc(ptr, bytes, hipHostMallocDefault));
+  return KH_OK;
+}
+
+KH_EXPORT int hipK_free_host(void *ptr) {
+  if (!ptr) return KH_OK;
+  KH_HIP(hipHostFree(ptr));
+  return KH_OK;
+}
+
+KH_EXPORT int hipK_memset_async(khStream_t s, void *ptr, int value, size_t bytes) {
+  KH_CHECK_INIT();
+  if (bytes == 0) return KH_OK;
+  KH_REQUIRE(ptr != nullptr);
+  KH_HIP(hipMemsetAsync(ptr, value, bytes, kh::pick(s)));
+  return KH_OK;
+}
+
+static hipMemcpyKind to_kind(int kind) {
+  return kind == 0 ? hipMemcpyHostToDevice : kind == 1 ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
+}
+
+KH_EXPORT int hipK_memcpy_2d(khStream_t s, void *dst, size_t dpitch, const void *src, size_t spitch,
+                             size_t width_bytes, size_t height, int kind) {
+  KH_CHECK_INIT();
+  if (width_bytes == 0 || height == 0) return KH_OK;
+  KH_REQUIRE(dst && src && kind >= 0 && kind <= 2 && dpitch >= width_bytes && spitch >= width_bytes);
+  hipStream_t st = kh::pick(s);
+  KH_HIP(hipMemcpy2DAsync(dst, dpitch, src, spitch, width_bytes, height, to_kind(kind), st));
+  if (kind != 2) KH_HIP(hipStreamSynchronize(st));
+  return KH_OK;
+}
+
+KH_EXPORT int hipK_memcpy(khStream_t s, void *dst, const void *src, size_t bytes, int kind) {
+  KH_CHECK_INIT();
+  if (bytes == 0) return KH_OK;
+  KH_REQUIRE(dst && src && kind >= 0 && kind <= 2);
+  hipStream_t st = kh::pick(s);
+  KH_HIP(hipMemcpyAsync(dst, src, bytes, to_kind(kind), st));
+  if (kind != 2) KH_HIP(hipStreamSynchronize(st));
+  return KH_OK;
+}
+
+KH_EXPORT int hipK_reserve_workspace(size_t bytes) {
+  KH_CHECK_INIT();
+  void *p;
+  return kh::ensure_workspace(bytes, &p);
+}

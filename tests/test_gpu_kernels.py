@@ -1,0 +1,505 @@
+"""GPU parity tests of the C-ABI kernels (include/kaldi_hip.h) against the CPU oracle.
+
+Shapes follow the reference's own cudamatrix unit test (src/cudamatrix/cuda-matrix-test.cc:
+100x111 element-wise, 4321x19 / 1000x990 reductions, 200x100 GEMMs) plus the RM/SWBD layer
+shapes of the hot path.  Tolerances: the reference test uses 1e-3 relative
+(cuda-matrix-test.cc:77-86); here element-wise ops are held to 1e-6, reductions/GEMMs to 1e-5
+of the row scale, integer outputs exactly.
+"""
+import ctypes
+
+import numpy as np
+import pytest
+
+from oracle import nnet1_oracle as O
+
+pytestmark = pytest.mark.gpu
+f32 = np.float32
+P = ctypes.c_void_p
+
+
+def dev(h, a, pitched=True):
+    return h.DevMatrix.from_numpy(np.asarray(a), pitched)
+
+
+def rnd(shape, seed, scale=1.0):
+    return (np.random.RandomState(seed).randn(*shape) * scale).astype(f32)
+
+
+def close(a, b, rtol=1e-6, atol=1e-6):
+    np.testing.assert_allclose(a, b, rtol=rtol, atol=atol)
+
+
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("shape", [(100, 111), (256, 2048), (7, 3), (1, 1)])
+def test_elementwise_unary_binary(hip, shape):
+    h = hip
+    x = rnd(shape, 1)
+    y = rnd(shape, 2)
+    # sigmoid / diff_sigmoid
+    dx, dy = dev(h, x), dev(h, np.zeros(shape, f32))
+    h.call("hipF_sigmoid", None, dy.ptr, dx.ptr, dx.dim)
+    s = O.sigmoid(x)
+    close(dy.numpy(), s, 2e-6, 1e-7)
+    de, dout = dev(h, y), dev(h, np.zeros(shape, f32))
+    h.call("hipF_diff_sigmoid", None, dout.ptr, de.ptr, dy.ptr, dy.dim)
+    close(dout.numpy(), O.diff_sigmoid(y, dy.numpy()), 2e-6, 1e-7)
+    # add_mat with beta (SGD update shape) and beta == 0 on NaN-filled dst
+    d1 = dev(h, x)
+    h.call("hipF_add_mat", None, f32(-0.008), dev(h, y).ptr, f32(1.0), d1.ptr, d1.dim)
+    close(d1.numpy(), (f32(-0.008) * y + x).astype(f32))
+    dn = dev(h, np.full(shape, np.nan, f32))
+    h.call("hipF_add_mat", None, f32(2.0), dev(h, y).ptr, f32(0.0), dn.ptr, dn.dim)
+    close(dn.numpy(), 2 * y)
+    # scale, add_const, apply_exp, apply_log, invert, power, floor, truncate, binarize, round
+    for name, args, ref in [
+        ("hipF_scale", (f32(0.5),), x * f32(0.5)),
+        ("hipF_add_const", (f32(1.5),), x + f32(1.5)),
+        ("hipF_apply_exp", (), np.exp(x)),
+        ("hipF_binarize", (f32(0.1),), (x > 0.1).astype(f32)),
+        ("hipF_round", (), np.where(x >= 0, np.floor(x + 0.5), np.ceil(x - 0.5))),
+        ("hipF_apply_floor", (f32(-0.2),), np.maximum(x, f32(-0.2))),
+        ("hipF_apply_truncate", (f32(-0.3), f32(0.4)), np.clip(x, f32(-0.3), f32(0.4))),
+    ]:
+        d = dev(h, x)
+        h.call(name, None, d.ptr, *args, d.dim)
+        close(d.numpy(), ref.astype(f32), 2e-6, 1e-7)
+    pos = np.abs(x) + f32(0.1)
+    d = dev(h, pos)
+    h.call("hipF_apply_log", None, d.ptr, d.dim)
+    close(d.numpy(), np.log(pos), 2e-6, 2e-7)
+    d = dev(h, pos)
+    h.call("hipF_invert_elements", None, d.ptr, d.dim)
+    close(d.numpy(), 1 / pos, 2e-6)
+    d = dev(h, pos)
+    h.call("hipF_power", None, d.ptr, f32(1.7), d.dim)
+    close(d.numpy(), np.power(pos, f32(1.7)), 5e-6)
+    # mul / div elements
+    d = dev(h, x)
+    h.call("hipF_mul_elements", None, d.ptr, dev(h, y).ptr, d.dim)
+    close(d.numpy(), x * y)
+    d = dev(h, x)
+    h.call("hipF_div_elements", None, d.ptr, dev(h, pos).ptr, d.dim)
+    close(d.numpy(), x / pos, 2e-6)
+    # relu family
+    d = dev(h, np.zeros(shape, f32))
+    h.call("hipF_relu", None, d.ptr, dx.ptr, dx.dim)
+    close(d.numpy(), np.maximum(x, 0))
+    h.call("hipF_diff_relu", None, d.ptr, de.ptr, dx.ptr, dx.dim)
+    close(d.numpy(), np.where(x > 0, y, 0))
+    h.call("hipF_softrelu", None, d.ptr, dx.ptr, dx.dim)
+    close(d.numpy(), np.where(x > 4, x, np.log1p(np.exp(x))), 3e-6, 1e-6)
+    h.call("hipF_diff_softrelu", None, d.ptr, de.ptr, dx.ptr, dx.dim)
+    close(d.numpy(), np.where(x > 4, y, y * np.exp(x) / (1 + np.exp(x))), 3e-6, 1e-6)
+    # log_add_exp_mat
+    d = dev(h, x)
+    h.call("hipF_log_add_exp_mat", None, dev(h, y).ptr, d.ptr, d.dim)
+    close(d.numpy(), np.logaddexp(x.astype(np.float64), y.astype(np.float64)).astype(f32), 2e-6, 1e-7)
+
+
+@pytest.mark.parametrize("shape", [(100, 111), (256, 1483), (33, 4)])
+def test_vector_broadcast_ops(hip, shape):
+    h = hip
+    R, C = shape
+    x = rnd(shape, 3)
+    col = rnd((C,), 4)
+    row = rnd((R,), 5)
+    dcol, drow = dev(h, col, False), dev(h, row, False)
+    for name, vec, ref in [
+        ("hipF_mul_cols_vec", dcol, x * col[None, :]),
+        ("hipF_mul_rows_vec", drow, x * row[:, None]),
+        ("hipF_div_cols_vec", dcol, x * (f32(1) / col)[None, :]),
+        ("hipF_div_rows_vec", drow, x * (f32(1) / row)[:, None]),
+    ]:
+        d = dev(h, x)
+        h.call(name, None, d.ptr, vec.ptr, d.dim)
+        close(d.numpy(), ref.astype(f32), 2e-6, 1e-7)
+    d = dev(h, x)
+    h.call("hipF_add_vec_to_rows", None, f32(0.5), dcol.ptr, f32(2.0), d.ptr, d.dim)
+    close(d.numpy(), f32(0.5) * col[None, :] + f32(2) * x)
+    d = dev(h, np.full(shape, np.nan, f32))
+    h.call("hipF_add_vec_to_rows", None, f32(1.0), dcol.ptr, f32(0.0), d.ptr, d.dim)  # bias pre-copy
+    close(d.numpy(), np.broadcast_to(col, shape))
+    d = dev(h, x)
+    h.call("hipF_add_vec_to_cols", None, f32(0.5), drow.ptr, f32(2.0), d.ptr, d.dim)
+    close(d.numpy(), f32(0.5) * row[:, None] + f32(2) * x)
+    # partial ops
+    d = dev(h, x)
+    h.call("hipF_part_set_const", None, d.ptr, f32(9.0), d.dim, 1, 2, 1, 2)
+    ref = x.copy()
+    ref[1:3, 1:3] = 9
+    close(d.numpy(), ref)
+    if C > 8:
+        d = dev(h, x)
+        sub = rnd((5,), 9)
+        h.call("hipF_add_vec_to_partial_rows", None, f32(2.0), 3, dev(h, sub, False).ptr, 5, f32(0.5), d.ptr, d.dim)
+        ref = x.copy()
+        ref[:, 3:8] = f32(2) * sub[None, :] + f32(0.5) * x[:, 3:8]
+        close(d.numpy(), ref)
+        a = rnd((4, 6), 10)
+        d = dev(h, x)
+        da = dev(h, a)
+        h.call("hipF_part_add_mat", None, f32(2.0), da.ptr, da.dim, 2, 1, f32(0.5), d.ptr, d.dim)
+        ref = x.copy()
+        ref[2:6, 1:7] = f32(2) * a + f32(0.5) * x[2:6, 1:7]
+        close(d.numpy(), ref)
+    di = h.DevMatrix(1, R, np.int32, pitched=False)
+    h.call("hipI32_set_const", None, di.ptr, -1, di.dim)
+    assert (di.numpy() == -1).all()
+
+
+@pytest.mark.parametrize("shape", [(4321, 19), (1000, 990), (256, 2048), (256, 9000), (5, 1)])
+def test_row_col_sums(hip, shape):
+    h = hip
+    R, C = shape
+    x = rnd(shape, 6)
+    v0 = rnd((C,), 7)
+    d = dev(h, x)
+    dv = dev(h, v0, False)
+    h.call("hipF_add_row_sum_mat", None, f32(0.7), d.ptr, d.dim, f32(0.5), dv.ptr)
+    ref = O.add_row_sum_mat(0.7, x, 0.5, v0)
+    close(dv.numpy()[0], ref, 1e-5, 1e-5 * np.sqrt(R))
+    v1 = rnd((R,), 8)
+    dv = dev(h, v1, False)
+    h.call("hipF_add_col_sum_mat", None, f32(0.7), d.ptr, d.dim, f32(0.5), dv.ptr)
+    close(dv.numpy()[0], O.add_col_sum_mat(0.7, x, 0.5, v1), 1e-5, 1e-5 * np.sqrt(C))
+    dv = dev(h, np.full((R,), np.nan, f32), False)
+    h.call("hipF_add_col_sum_mat", None, f32(1.0), d.ptr, d.dim, f32(0.0), dv.ptr)
+    close(dv.numpy()[0], O.add_col_sum_mat(1.0, x, 0.0, np.zeros(R, f32)), 1e-5, 1e-5 * np.sqrt(C))
+
+
+@pytest.mark.parametrize("shape", [(100, 111), (256, 1483), (256, 9000), (3, 13001), (2, 1)])
+def test_softmax(hip, shape):
+    h = hip
+    x = rnd(shape, 11, 3.0)
+    d = dev(h, x)
+    y = dev(h, np.zeros(shape, f32))
+    h.call("hipF_softmax", None, y.ptr, d.ptr, d.dim)
+    got = y.numpy()
+    ref = O.softmax(x)
+    # north_star: posteriors within 1e-4 relative
+    np.testing.assert_allclose(got, ref, rtol=1e-4, atol=1e-30)
+    close(got.sum(1), np.ones(shape[0]), 1e-5)
+    h.call("hipF_softmax", None, d.ptr, d.ptr, d.dim)  # in place
+    np.testing.assert_allclose(d.numpy(), ref, rtol=1e-4, atol=1e-30)
+
+
+def test_softmax_part_and_argmax_ties(hip):
+    h = hip
+    x = rnd((37, 600), 12)
+    x[3, 10] = x[3, 500] = 10.0      # tie: the first maximum wins
+    x[4, 0] = x[4, 599] = 11.0
+    x[5, :] = 2.5                    # all equal -> index 0
+    x[6, :] = -2e21                  # nothing exceeds the -1e21 start value -> -1
+    d = dev(h, x)
+    ids = h.DevMatrix(1, 37, np.int32, pitched=False)
+    vals = h.DevMatrix(1, 37, f32, pitched=False)
+    h.call("hipF_find_row_max_id", None, d.ptr, vals.ptr, ids.ptr, d.dim)
+    ref = O.find_row_max_id(x)
+    got = ids.numpy()[0]
+    assert (got == ref).all()
+    assert got[3] == 10 and got[4] == 0 and got[5] == 0 and got[6] == -1
+    ok = ref >= 0
+    close(vals.numpy()[0][ok], x[np.arange(37)[ok], ref[ok]])
+    ids2 = dev(h, np.where(ref < 0, 0, ref).astype(np.int32), False)
+    y = dev(h, np.zeros_like(x))
+    h.call("hipF_softmax_part", None, d.ptr, ids2.ptr, y.ptr, d.dim)
+    xx = x[:6]
+    close(y.numpy()[:6], np.exp(xx - xx.max(1, keepdims=True)), 3e-6, 1e-30)
+
+
+@pytest.mark.parametrize("shape", [(256, 1483), (256, 9000), (16, 17)])
+def test_xent(hip, shape):
+    h = hip
+    R, C = shape
+    rs = np.random.RandomState(13)
+    post = O.softmax(rnd(shape, 14, 2.0))
+    tgt = rs.randint(0, C, R).astype(np.int32)
+    tgt[: R // 4] = post[: R // 4].argmax(1)   # make a known share of the frames correct
+    post[1, tgt[1]] = 0.0                       # exercises the 1e-20 floor
+    # separate kernel
+    d = dev(h, post)
+    dt = dev(h, tgt, False)
+    lp = h.DevMatrix(1, R, f32, pitched=False)
+    h.call("hipF_diff_xent", None, dt.ptr, d.ptr, lp.ptr, d.dim)
+    rdiff, rlp = O.diff_xent(tgt, post)
+    close(d.numpy(), rdiff)
+    close(lp.numpy()[0], rlp, 2e-6)
+    # fused evaluation, out of place and in place, two calls accumulate
+    x = O.Xent()
+    rdiff, rlp, rmax, rcorrect = x.eval_vec(post, tgt)
+    cnt = h.DevMatrix(1, 2, np.int64, pitched=False)
+    loss = h.DevMatrix(1, 1, np.float64, pitched=False)
+    dp, dd = dev(h, post), dev(h, np.zeros(shape, f32))
+    mid = h.DevMatrix(1, R, np.int32, pitched=False)
+    h.call("hipF_xent_eval", None, dp.ptr, dt.ptr, dd.ptr, lp.ptr, mid.ptr, cnt.ptr, loss.ptr, dp.dim)
+    close(dd.numpy(), rdiff)
+    assert (mid.numpy()[0] == rmax).all()
+    assert cnt.numpy()[0].tolist() == [rcorrect, R]           # frame-accuracy counts exactly
+    assert abs(loss.numpy()[0, 0] - x.loss) <= 1e-5 * abs(x.loss)
+    h.call("hipF_xent_eval", None, dp.ptr, dt.ptr, dp.ptr, None, None, cnt.ptr, loss.ptr, dp.dim)  # in place
+    close(dp.numpy(), rdiff)
+    assert cnt.numpy()[0].tolist() == [2 * rcorrect, 2 * R]
+    assert abs(loss.numpy()[0, 0] - 2 * x.loss) <= 1e-5 * abs(2 * x.loss)
+
+
+def test_mse_eval(hip):
+    h = hip
+    a, b = rnd((256, 440), 15), rnd((256, 440), 16)
+    rdiff, rrow, rloss = O.mse_eval(a, b)
+    da, db, dd = dev(h, a), dev(h, b), dev(h, np.zeros_like(a))
+    row = h.DevMatrix(1, 256, f32, pitched=False)
+    loss = h.DevMatrix(1, 1, np.float64, pitched=False)
+    h.call("hipF_mse_eval", None, da.ptr, db.ptr, dd.ptr, row.ptr, loss.ptr, da.dim)
+    close(dd.numpy(), rdiff)
+    close(row.numpy()[0], rrow, 1e-5)
+    assert abs(loss.numpy()[0, 0] - rloss) < 1e-5 * rloss
+
+
+def test_gathers(hip):
+    h = hip
+    rs = np.random.RandomState(17)
+    src = rnd((1000, 440), 18)
+    idx = rs.permutation(1000)[:777].astype(np.int32)
+    d, di = dev(h, src), dev(h, idx, False)
+    out = dev(h, np.zeros((1000, 440), f32))
+    dout = out.dim
+    dout.rows = 777
+    h.call("hipF_randomize", None, out.ptr, d.ptr, di.ptr, dout, d.dim)
+    assert (out.numpy()[:777] == O.randomize(src, idx)).all()     # bit exact: it is a copy
+    assert (out.numpy()[777:] == 0).all()
+    # unaligned width takes the scalar path
+    src2 = rnd((50, 39), 19)
+    idx2 = rs.permutation(50).astype(np.int32)
+    d2, out2 = dev(h, src2, False), dev(h, np.zeros((50, 39), f32), False)
+    h.call("hipF_randomize", None, out2.ptr, d2.ptr, dev(h, idx2, False).ptr, out2.dim, d2.dim)
+    assert (out2.numpy() == src2[idx2]).all()
+    # splice +-5 like the recipes (40 -> 440)
+    feats = rnd((123, 40), 20)
+    offs = np.arange(-5, 6).astype(np.int32)
+    df, do = dev(h, feats), dev(h, np.zeros((123, 440), f32))
+    h.call("hipF_expand", None, do.ptr, df.ptr, dev(h, offs, False).ptr, do.dim, df.dim)
+    assert (do.numpy() == O.expand(feats, offs)).all()
+    # column gather with one bad index -> +inf
+    cidx = rs.randint(0, 40, 25).astype(np.int32)
+    cidx[7] = 40
+    dc = dev(h, np.zeros((123, 25), f32))
+    h.call("hipF_copy", None, dc.ptr, df.ptr, dev(h, cidx, False).ptr, dc.dim, df.dim)
+    got = dc.numpy()
+    good = np.arange(25) != 7
+    assert (got[:, good] == feats[:, cidx[good]]).all() and np.isposinf(got[:, 7]).all()
+
+
+def test_hybrid_taus_bit_exact(hip):
+    h = hip
+    rs = np.random.RandomState(21)
+    shape = (64, 200)
+    z = [rs.randint(128, 2 ** 31 - 1, shape).astype(np.uint32) for _ in range(4)]
+    dz = [dev(h, a) for a in z]
+    out = dev(h, np.zeros(shape, f32))
+    zz = z
+    for _ in range(3):  # state carries over between calls
+        h.call("hipF_rand", None, out.ptr, dz[0].ptr, dz[1].ptr, dz[2].ptr, dz[3].ptr, out.dim)
+        ref, zz = O.hybrid_taus(*zz)
+        assert (out.numpy() == ref).all()
+    for a, b in zip(dz, zz):
+        assert (a.numpy() == b).all()
+    # gaussian: same uniforms, Box-Muller in float -> a few ulp
+    h.call("hipF_gauss_rand", None, out.ptr, dz[0].ptr, dz[1].ptr, dz[2].ptr, dz[3].ptr, out.dim)
+    ref, zz2 = O.box_muller(*zz)
+    close(out.numpy(), ref, 1e-4, 1e-5)
+    for a, b in zip(dz, zz2):
+        assert (a.numpy() == b).all()
+    # fused binarize == rand + compare
+    probs = rs.rand(*shape).astype(f32)
+    st = dev(h, np.zeros(shape, f32))
+    h.call("hipF_binarize_probs_rand", None, st.ptr, dev(h, probs).ptr, dz[0].ptr, dz[1].ptr, dz[2].ptr, dz[3].ptr,
+           st.dim)
+    u, zz3 = O.hybrid_taus(*zz2)
+    assert (st.numpy() == O.binarize_probs(probs, u)).all()
+    # unfused binarize
+    du = dev(h, u)
+    h.call("hipF_binarize_probs", None, st.ptr, dev(h, probs).ptr, du.ptr, st.dim)
+    assert (st.numpy() == O.binarize_probs(probs, u)).all()
+    # statistics of a long run: mean 0.5, var 1/12
+    big = (512, 2048)
+    zb = [dev(h, rs.randint(128, 2 ** 31 - 1, big).astype(np.uint32)) for _ in range(4)]
+    ob = dev(h, np.zeros(big, f32))
+    h.call("hipF_rand", None, ob.ptr, zb[0].ptr, zb[1].ptr, zb[2].ptr, zb[3].ptr, ob.dim)
+    v = ob.numpy().astype(np.float64)
+    assert abs(v.mean() - 0.5) < 2e-3 and abs(v.var() - 1 / 12) < 2e-3 and v.min() > 0 and v.max() < 1
+    m0 = rnd(big, 22)
+    om = dev(h, m0)
+    h.call("hipF_add_gauss_noise", None, om.ptr, f32(1.0), zb[0].ptr, zb[1].ptr, zb[2].ptr, zb[3].ptr, om.dim)
+    g = om.numpy().astype(np.float64) - m0
+    assert abs(g.mean()) < 5e-3 and abs(g.var() - 1.0) < 1e-2
+
+
+GEMM_SHAPES = [
+    # (M, N, K)
+    (200, 200, 100),          # the reference's own test shape
+    (256, 1024, 440), (256, 1483, 1024), (256, 1024, 1483), (1024, 440, 256), (1483, 1024, 256),
+    (256, 2048, 2048), (2048, 2048, 256), (256, 9000, 2048),
+    (1, 1, 1), (33, 65, 7), (64, 64, 32), (130, 70, 33),
+]
+
+
+@pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
+@pytest.mark.parametrize("ta,tb", [(0, 1), (0, 0), (1, 0), (1, 1)])
+def test_gemm(hip, M, N, K, ta, tb):
+    h = hip
+    if M * N * K > 3e8 and (ta, tb) == (1, 1):
+        pytest.skip("TT does not occur on the path; small shapes cover it")
+    A = rnd((K, M) if ta else (M, K), 30)
+    B = rnd((N, K) if tb else (K, N), 31)
+    C0 = rnd((M, N), 32)
+    dA, dB, dC = dev(h, A), dev(h, B), dev(h, C0)
+    scale = np.sqrt(K)
+    for alpha, beta in [(1.0, 0.0), (0.5, 1.0), (-0.25, 0.9)]:
+        dC.set(C0 if beta != 0 else np.full((M, N), np.nan, f32))
+        h.call("hipF_gemm", None, h.TRANS if ta else h.NO_TRANS, h.TRANS if tb else h.NO_TRANS, M, N, K, f32(alpha),
+               dA.ptr, dA.stride, dB.ptr, dB.stride, f32(beta), dC.ptr, dC.stride)
+        ref = O.gemm(alpha, A, ta, B, tb, beta, C0)
+        np.testing.assert_allclose(dC.numpy(), ref, rtol=1e-5, atol=2e-6 * scale)
+
+
+def test_gemm_unaligned_and_exact(hip):
+    """Tight (unpitched) operands take the scalar-load path; small integers make the sum exact,
+    and an asymmetric B catches a transposed output map."""
+    h = hip
+    rs = np.random.RandomState(33)
+    M, N, K = 70, 45, 37
+    A = rs.randint(-3, 4, (M, K)).astype(f32)
+    B = rs.randint(-3, 4, (K, N)).astype(f32)
+    dA, dB, dC = dev(h, A, False), dev(h, B, False), dev(h, np.zeros((M, N), f32), False)
+    h.call("hipF_gemm", None, h.NO_TRANS, h.NO_TRANS, M, N, K, f32(1), dA.ptr, K, dB.ptr, N, f32(0), dC.ptr, N)
+    assert (dC.numpy() == A @ B).all()
+    I = np.eye(64, dtype=f32)
+    Bm = (np.arange(64 * 64).reshape(64, 64) % 251).astype(f32)
+    dI, dB2, dC2 = dev(h, I), dev(h, Bm), dev(h, np.zeros((64, 64), f32))
+    h.call("hipF_gemm", None, h.NO_TRANS, h.NO_TRANS, 64, 64, 64, f32(1), dI.ptr, dI.stride, dB2.ptr, dB2.stride,
+           f32(0), dC2.ptr, dC2.stride)
+    assert (dC2.numpy() == Bm).all()
+    # K = 0: C = beta*C
+    h.call("hipF_gemm", None, h.NO_TRANS, h.NO_TRANS, 64, 64, 0, f32(1), None, 64, None, 64, f32(2), dC2.ptr,
+           dC2.stride)
+    assert (dC2.numpy() == 2 * Bm).all()
+    # run-to-run reproducibility (fixed summation order, no atomics)
+    A2, B2 = rnd((256, 2048), 34), rnd((2048, 2048), 35)
+    dA2, dB3 = dev(h, A2), dev(h, B2)
+    outs = []
+    for _ in range(3):
+        dC3 = dev(h, np.zeros((256, 2048), f32))
+        h.call("hipF_gemm", None, h.NO_TRANS, h.TRANS, 256, 2048, 2048, f32(1), dA2.ptr, dA2.stride, dB3.ptr,
+               dB3.stride, f32(0), dC3.ptr, dC3.stride)
+        outs.append(dC3.numpy())
+    assert (outs[0] == outs[1]).all() and (outs[0] == outs[2]).all()
+
+
+AFFINE_SHAPES = [(256, 1024, 440), (256, 1483, 1024), (256, 2048, 1320), (256, 2048, 2048), (256, 9000, 2048),
+                 (16, 17, 24), (100, 33, 50)]
+
+
+@pytest.mark.parametrize("N,O_,I", AFFINE_SHAPES)
+def test_affine_forward_backward_update(hip, N, O_, I):
+    h = hip
+    x = rnd((N, I), 40)
+    W = rnd((O_, I), 41, 0.1)
+    b = rnd((O_,), 42, 0.5)
+    layer = O.BiasedLinearity(W, b)
+    dx, dW, db = dev(h, x), dev(h, W), dev(h, b, False)
+    out = dev(h, np.full((N, O_), np.nan, f32))
+    pre = layer.propagate(x)
+    for act, ref in [(h.ACT_NONE, pre), (h.ACT_SIGMOID, O.sigmoid(pre)), (h.ACT_SOFTMAX, O.softmax(pre))]:
+        h.call("hipF_affine_forward", None, act, h.TRANS, N, O_, I, dx.ptr, dx.stride, dW.ptr, dW.stride, db.ptr,
+               out.ptr, out.stride)
+        got = out.numpy()
+        if act == h.ACT_SOFTMAX:
+            np.testing.assert_allclose(got, ref, rtol=1e-4, atol=1e-12)
+        else:
+            np.testing.assert_allclose(got, ref, rtol=1e-5, atol=3e-6 * np.sqrt(I))
+    # backward with and without the sigmoid derivative of the layer below
+    e = rnd((N, O_), 43, 0.01)
+    y = O.sigmoid(rnd((N, I), 44))
+    de, dy = dev(h, e), dev(h, y)
+    eout = dev(h, np.full((N, I), np.nan, f32))
+    ref_lin = layer.backpropagate(e)
+    h.call("hipF_affine_backward", None, N, O_, I, de.ptr, de.stride, dW.ptr, dW.stride, None, 0, eout.ptr,
+           eout.stride)
+    np.testing.assert_allclose(eout.numpy(), ref_lin, rtol=1e-5, atol=3e-8 * np.sqrt(O_))
+    h.call("hipF_affine_backward", None, N, O_, I, de.ptr, de.stride, dW.ptr, dW.stride, dy.ptr, dy.stride, eout.ptr,
+           eout.stride)
+    np.testing.assert_allclose(eout.numpy(), O.diff_sigmoid(ref_lin, y), rtol=1e-5, atol=1e-8 * np.sqrt(O_))
+    # two SGD steps with momentum, L2 and averaged gradient; then plain (momentum 0, no corr buffers)
+    for (mom, l2, avg) in [(0.9, 1e-4, True), (0.0, 0.0, False)]:
+        layer = O.BiasedLinearity(W, b)
+        layer.learn_rate, layer.momentum, layer.l2_penalty, layer.average_grad = f32(0.008), f32(mom), f32(l2), avg
+        dW.set(W)
+        db.set(b)
+        corr, bcorr = dev(h, np.zeros_like(W)), dev(h, np.zeros_like(b), False)
+        for step in range(2):
+            layer.update(x, e)
+            g = f32(1.0 / N) if avg else f32(1.0)
+            l2s = f32(f32(0.008) * f32(l2) * N) if l2 else f32(0)
+            use_corr = mom != 0
+            h.call("hipF_affine_update", None, N, O_, I, de.ptr, de.stride, dx.ptr, dx.stride, g, f32(mom),
+                   f32(0.008), l2s, dW.ptr, dW.stride, corr.ptr if use_corr else None, corr.stride,
+                   db.ptr, bcorr.ptr if use_corr else None)
+            # north_star: gradients / updated weights within 1e-3 relative
+            np.testing.assert_allclose(dW.numpy(), layer.W, rtol=1e-5, atol=1e-7)
+            np.testing.assert_allclose(db.numpy()[0], layer.b, rtol=1e-5, atol=1e-7)
+            if use_corr:
+                np.testing.assert_allclose(corr.numpy(), layer.W_corr, rtol=1e-4, atol=1e-7)
+                np.testing.assert_allclose(bcorr.numpy()[0], layer.b_corr, rtol=1e-4, atol=1e-7)
+
+
+@pytest.mark.parametrize("V,H,vt,ht", [(440, 2048, "gauss", "bern"), (2048, 2048, "bern", "bern"), (24, 32, "bern", "gauss")])
+def test_rbm_cd1(hip, V, H, vt, ht):
+    h = hip
+    N = 256
+    rs = np.random.RandomState(50)
+    W = rnd((H, V), 51, 0.1)
+    vb, hb = rnd((V,), 52, 0.1), rnd((H,), 53, 0.1)
+    pos_vis = rnd((N, V), 54) if vt == "gauss" else rs.rand(N, V).astype(f32)
+    u = rs.rand(N, H).astype(f32)
+    g = rnd((N, H), 55)
+    rbm = O.Rbm(W, vb, hb, vt, ht)
+    rbm.learn_rate, rbm.momentum, rbm.l2_penalty = f32(0.01), f32(0.5), f32(2e-4)
+    dW, dvb, dhb = dev(h, W), dev(h, vb, False), dev(h, hb, False)
+    ddW, ddvb, ddhb = dev(h, np.zeros_like(W)), dev(h, np.zeros_like(vb), False), dev(h, np.zeros_like(hb), False)
+    dpv = dev(h, pos_vis)
+    dph, dnh, dnv = dev(h, np.zeros((N, H), f32)), dev(h, np.zeros((N, H), f32)), dev(h, np.zeros((N, V), f32))
+    hact = h.ACT_SIGMOID if ht == "bern" else h.ACT_NONE
+    vact = h.ACT_SIGMOID if vt == "bern" else h.ACT_NONE
+    for step in range(2):
+        ref = O.rbm_cd1_step(rbm, pos_vis, uniform=u, gauss=g)
+        h.call("hipF_affine_forward", None, hact, h.TRANS, N, H, V, dpv.ptr, dpv.stride, dW.ptr, dW.stride, dhb.ptr,
+               dph.ptr, dph.stride)
+        np.testing.assert_allclose(dph.numpy(), ref["pos_hid"], rtol=1e-5, atol=3e-6)
+        # the sample is injected from the oracle so that a last-ulp flip cannot change the comparison
+        dsample = dev(h, ref["neg_hid_sample"])
+        h.call("hipF_affine_forward", None, vact, h.NO_TRANS, N, V, H, dsample.ptr, dsample.stride, dW.ptr, dW.stride,
+               dvb.ptr, dnv.ptr, dnv.stride)
+        np.testing.assert_allclose(dnv.numpy(), ref["neg_vis"], rtol=2e-5, atol=2e-5)
+        h.call("hipF_affine_forward", None, hact, h.TRANS, N, H, V, dnv.ptr, dnv.stride, dW.ptr, dW.stride, dhb.ptr,
+               dnh.ptr, dnh.stride)
+        np.testing.assert_allclose(dnh.numpy(), ref["neg_hid"], rtol=2e-5, atol=2e-5)
+        h.call("hipF_rbm_update", None, N, H, V, dpv.ptr, dpv.stride, dph.ptr, dph.stride, dnv.ptr, dnv.stride,
+               dnh.ptr, dnh.stride, f32(0.01), f32(0.5), f32(2e-4), dW.ptr, dW.stride, ddW.ptr, ddW.stride, dvb.ptr,
+               ddvb.ptr, dhb.ptr, ddhb.ptr)
+        np.testing.assert_allclose(dW.numpy(), rbm.W, rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(ddW.numpy(), rbm.W_corr, rtol=1e-3, atol=1e-7)
+        np.testing.assert_allclose(dvb.numpy()[0], rbm.vis_bias, rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(dhb.numpy()[0], rbm.hid_bias, rtol=1e-4, atol=1e-6)
+
+
+def test_argument_checks(hip):
+    h = hip
+    bad = h.MatrixDim(4, 8, 4)  # stride < cols
+    assert h.lib.hipF_sigmoid(None, P(16), P(16), bad) == 100001
+    assert b"requirement" in h.lib.hipK_error_string(100001)
+    assert h.lib.hipF_gemm(None, 5, h.TRANS, 4, 4, 4, f32(1), P(16), 4, P(16), 4, f32(0), P(16), 4) == 100001
+    assert h.lib.hipF_gemm(None, h.NO_TRANS, h.TRANS, 4, 4, 4, f32(1), P(16), 2, P(16), 4, f32(0), P(16), 4) == 100001
+    # empty matrices are a no-op
+    assert h.lib.hipF_sigmoid(None, None, None, h.MatrixDim(0, 0, 0)) == 0
+    assert h.lib.hipF_softmax(None, None, None, h.MatrixDim(0, 5, 5)) == 0
