@@ -76,6 +76,15 @@ const char *hipK_error_string(int status);
 /* compute units, wave size, gcn arch name ("gfx950...") of the active device */
 int hipK_device_props(int *num_cu, int *wave_size, char *arch_name, size_t arch_name_len);
 
+/* Events for timing on a stream (the reference timed with host Timer + device sync,
+ * cu-matrix-inl.h:349-357; events do not stall the stream). */
+typedef void *khEvent_t; /* hipEvent_t */
+int hipK_event_create(khEvent_t *ev);
+int hipK_event_destroy(khEvent_t ev);
+int hipK_event_record(khEvent_t ev, khStream_t s);
+int hipK_event_synchronize(khEvent_t ev); /* blocking */
+int hipK_event_elapsed_ms(float *ms, khEvent_t start, khEvent_t stop);
+
 /* cudaMallocPitch (cu-matrix-inl.h:108): rows x cols floats, row pitch rounded up so that every
  * row starts 256-byte aligned; *stride_elems receives the pitch in elements.  Not zeroed. */
 int hipK_malloc_pitch(void **ptr, int32_t *stride_elems, int32_t rows, int32_t cols, size_t elem_size);
@@ -170,7 +179,8 @@ int hipF_regularize_l1(khStream_t s, float *wei, float *grad, float l1, float lr
 int hipF_find_row_max_id(khStream_t s, const float *mat, float *vec_val, int32_t *vec_id, MatrixDim d);
 /* vec_log_post[r] = log(max(mat[r,tgt[r]], 1e-20)); mat[r,tgt[r]] -= 1  (cu-kernels.cu:733-745) */
 int hipF_diff_xent(khStream_t s, const int32_t *vec_tgt, float *mat_net_out, float *vec_log_post, MatrixDim d);
-/* y[r,:] = x[copy_from[r],:] for r < d_out.rows (cu-kernels.cu:661-669) */
+/* y[r,:] = x[copy_from[r],:] for r < d_out.rows (cu-kernels.cu:661-669).  d_in describes all of x:
+ * an index outside [0, d_in.rows) leaves that output row untouched instead of reading out of bounds. */
 int hipF_randomize(khStream_t s, float *y, const float *x, const int32_t *copy_from, MatrixDim d_out,
                    MatrixDim d_in);
 /* splice: y[r, k*D+c] = x[clamp(r+off[k], 0, rows-1), c]  (cu-kernels.cu:627-638) */
@@ -243,6 +253,16 @@ int hipF_affine_update(khStream_t s, int32_t N, int32_t O, int32_t I, const floa
                        const float *in, int32_t ldin, float gscale, float momentum, float lr, float l2,
                        float *W, int32_t ldw, float *corr, int32_t ldcorr, float *bias, float *bcorr);
 
+/* Data-parallel form of the update, second half (the first half is a plain hipF_gemm into a dense
+ * gradient buffer plus hipF_add_row_sum_mat, all-reduced across ranks by the caller):
+ *   corr = gscale * grad + momentum * corr ;  W = (1 - l2) * W - lr * corr      (grad OxI, ld ldg)
+ *   bcorr = gscale * bgrad + momentum * bcorr ;  b = b - lr * bcorr
+ * Same arithmetic, element for element, as hipF_affine_update's epilogue.  corr / bcorr may be
+ * NULL only when momentum == 0. */
+int hipF_affine_apply(khStream_t s, int32_t O, int32_t I, const float *grad, int32_t ldg, const float *bgrad,
+                      float gscale, float momentum, float lr, float l2, float *W, int32_t ldw, float *corr,
+                      int32_t ldcorr, float *bias, float *bcorr);
+
 /* Xent::EvalVec on the device (nnet-loss.cc:59-94 = cu::FindRowMaxId + host compare +
  * cu::DiffXent + host sum), one pass over the posteriors:
  *   diff = post - onehot(tgt)           (diff may alias post)
@@ -284,6 +304,9 @@ int hipK_comm_rank(int *rank, int *nranks);
 int hipF_allreduce_sum(khStream_t s, float *buf, size_t count);
 int hipK_allreduce_sum_f64(khStream_t s, double *buf, size_t count);
 int hipK_allreduce_sum_i64(khStream_t s, long long *buf, size_t count);
+/* in-place all-reduce of count int64 with op 0 = sum, 1 = min, 2 = max (control-plane scalars:
+ * "how many bunches does every rank have", "has any rank run out of data") */
+int hipK_allreduce_i64(khStream_t s, long long *buf, size_t count, int op);
 int hipK_comm_barrier(khStream_t s);
 
 #ifdef __cplusplus

@@ -1,0 +1,152 @@
+// Token / basic-type stream I/O in Kaldi's on-disk conventions (reference base/io-funcs.h,
+// io-funcs-inl.h:30-213, io-funcs.cc:23-202):
+//   binary integers : one size byte (+sizeof for signed, -sizeof for unsigned) then the raw
+//                     little-endian value;  text: decimal followed by a space
+//   binary floats   : size byte (4 or 8) then raw value; readers accept either width
+//   tokens          : the characters followed by ONE space, in both modes
+//   stream header   : "\0B" marks a binary stream
+#ifndef KALDI_AMD_BASE_IO_FUNCS_H_
+#define KALDI_AMD_BASE_IO_FUNCS_H_
+#include <iostream>
+#include <limits>
+#include <string>
+#include <type_traits>
+#include <vector>
+
+#include "base/kaldi-error.h"
+#include "base/kaldi-types.h"
+
+namespace kaldi {
+
+void WriteToken(std::ostream &os, bool binary, const char *token);
+void WriteToken(std::ostream &os, bool binary, const std::string &token);
+void ReadToken(std::istream &is, bool binary, std::string *token);
+/// next character without consuming it (whitespace skipped first in text mode); EOF -> -1
+int Peek(std::istream &is, bool binary);
+/// first character of the next token, looking past a leading '<'
+int PeekToken(std::istream &is, bool binary);
+void ExpectToken(std::istream &is, bool binary, const char *token);
+void ExpectToken(std::istream &is, bool binary, const std::string &token);
+
+template <class T>
+typename std::enable_if<std::is_integral<T>::value && !std::is_same<T, bool>::value>::type WriteBasicType(
+    std::ostream &os, bool binary, T t) {
+  if (binary) {
+    const char len = static_cast<char>(std::numeric_limits<T>::is_signed ? sizeof(T) : -static_cast<int>(sizeof(T)));
+    os.put(len);
+    os.write(reinterpret_cast<const char *>(&t), sizeof(T));
+  } else if (sizeof(T) == 1) {
+    os << static_cast<int16>(t) << " ";
+  } else {
+    os << t << " ";
+  }
+  if (os.fail()) throw std::runtime_error("Write failure in WriteBasicType.");
+}
+
+template <class T>
+typename std::enable_if<std::is_integral<T>::value && !std::is_same<T, bool>::value>::type ReadBasicType(
+    std::istream &is, bool binary, T *t) {
+  if (binary) {
+    const int got = is.get();
+    if (got == -1) KALDI_ERR << "ReadBasicType: encountered end of stream.";
+    const char want = static_cast<char>(std::numeric_limits<T>::is_signed ? sizeof(T) : -static_cast<int>(sizeof(T)));
+    if (static_cast<char>(got) != want)
+      KALDI_ERR << "ReadBasicType: did not get expected integer type, " << static_cast<int>(static_cast<char>(got))
+                << " vs. " << static_cast<int>(want);
+    is.read(reinterpret_cast<char *>(t), sizeof(T));
+  } else if (sizeof(T) == 1) {
+    int16 tmp;
+    is >> tmp;
+    *t = static_cast<T>(tmp);
+  } else {
+    is >> *t;
+  }
+  if (is.fail()) KALDI_ERR << "Read failure in ReadBasicType, file position is " << is.tellg();
+}
+
+void WriteBasicType(std::ostream &os, bool binary, bool b);
+void WriteBasicType(std::ostream &os, bool binary, float f);
+void WriteBasicType(std::ostream &os, bool binary, double f);
+void ReadBasicType(std::istream &is, bool binary, bool *b);
+void ReadBasicType(std::istream &is, bool binary, float *f);
+void ReadBasicType(std::istream &is, bool binary, double *f);
+
+template <class T>
+void WriteIntegerVector(std::ostream &os, bool binary, const std::vector<T> &v) {
+  static_assert(std::is_integral<T>::value, "integer vectors only");
+  if (binary) {
+    const char sz = sizeof(T);
+    os.write(&sz, 1);
+    const int32 n = static_cast<int32>(v.size());
+    os.write(reinterpret_cast<const char *>(&n), sizeof(n));
+    if (n != 0) os.write(reinterpret_cast<const char *>(v.data()), sizeof(T) * n);
+  } else {
+    os << "[ ";
+    for (size_t i = 0; i < v.size(); ++i) {
+      if (sizeof(T) == 1) os << static_cast<int16>(v[i]) << " ";
+      else os << v[i] << " ";
+    }
+    os << "]\n";
+  }
+  if (os.fail()) throw std::runtime_error("Write failure in WriteIntegerVector.");
+}
+
+template <class T>
+void ReadIntegerVector(std::istream &is, bool binary, std::vector<T> *v) {
+  static_assert(std::is_integral<T>::value, "integer vectors only");
+  if (binary) {
+    const int sz = is.get();
+    if (sz != static_cast<int>(sizeof(T)))
+      KALDI_ERR << "ReadIntegerVector: expected to see type of size " << sizeof(T) << ", saw instead " << sz;
+    int32 n = -1;
+    is.read(reinterpret_cast<char *>(&n), sizeof(n));
+    if (is.fail() || n < 0) KALDI_ERR << "ReadIntegerVector: read failure at file position " << is.tellg();
+    v->resize(n);
+    if (n > 0) is.read(reinterpret_cast<char *>(v->data()), sizeof(T) * n);
+  } else {
+    std::vector<T> tmp;
+    is >> std::ws;
+    if (is.get() != '[') KALDI_ERR << "ReadIntegerVector: expected to see [ at file position " << is.tellg();
+    is >> std::ws;
+    while (is.peek() != ']') {
+      if (sizeof(T) == 1) {
+        int16 x;
+        is >> x >> std::ws;
+        tmp.push_back(static_cast<T>(x));
+      } else {
+        T x;
+        is >> x >> std::ws;
+        tmp.push_back(x);
+      }
+      if (is.fail()) KALDI_ERR << "ReadIntegerVector: read failure at file position " << is.tellg();
+    }
+    is.get();
+    v->swap(tmp);
+  }
+  if (is.fail()) KALDI_ERR << "ReadIntegerVector: read failure at file position " << is.tellg();
+}
+
+/// writes "\0B" in binary mode and raises the float print precision to 7 digits
+inline void InitKaldiOutputStream(std::ostream &os, bool binary) {
+  if (binary) {
+    os.put('\0');
+    os.put('B');
+  }
+  if (os.precision() < 7) os.precision(7);
+}
+
+/// detects the "\0B" header; false only for a '\0' not followed by 'B'
+inline bool InitKaldiInputStream(std::istream &is, bool *binary) {
+  if (is.peek() == '\0') {
+    is.get();
+    if (is.peek() != 'B') return false;
+    is.get();
+    *binary = true;
+  } else {
+    *binary = false;
+  }
+  return true;
+}
+
+}  // namespace kaldi
+#endif

@@ -1,0 +1,239 @@
+#include "capi/nnet1_capi.h"
+
+#include <string>
+
+#include "cudamatrix/cu-rand.h"
+#include "nnet/nnet-biasedlinearity.h"
+#include "nnet/nnet-loss.h"
+#include "nnet/nnet-nnet.h"
+#include "nnet/nnet-rbm.h"
+
+using namespace kaldi;
+
+namespace {
+thread_local std::string g_error;
+
+struct Trainer {
+  Nnet nnet;
+  Xent xent;
+  CuMatrix<BaseFloat> nnet_in, nnet_out, glob_err;
+  CuStlVector<int32> targets;
+};
+
+struct RbmTrainer {
+  Nnet nnet;
+  CuRand<BaseFloat> cu_rand;
+  MseProgress mse;
+  CuMatrix<BaseFloat> pos_vis, pos_hid, neg_vis, neg_hid, dummy;
+};
+
+// device rows (ld) -> CuMatrix, the copy Cache::GetBunch makes
+void CopyIn(const float *dev, int ld, int rows, int cols, CuMatrix<BaseFloat> *m) {
+  m->Resize(rows, cols);
+  CU_SAFE_CALL(hipK_memcpy_2d(CuDevice::Instantiate().Stream(), m->Data(), m->Stride() * sizeof(float), dev,
+                              ld * sizeof(float), cols * sizeof(float), rows, 2));
+}
+}  // namespace
+
+#define CAPI_TRY try {
+#define CAPI_CATCH(ret)              \
+  }                                  \
+  catch (const std::exception &e) {  \
+    g_error = e.what();              \
+    return ret;                      \
+  }
+
+extern "C" {
+
+const char *nnet1_last_error(void) { return g_error.c_str(); }
+
+int nnet1_select_gpu(int gpu_id) {
+  CAPI_TRY
+  CuDevice::Instantiate().Verbose(false);
+  CuDevice::Instantiate().SelectGpuId(gpu_id);
+  return 0;
+  CAPI_CATCH(-1)
+}
+
+void *nnet1_create(const char *model) {
+  CAPI_TRY
+  CuDevice::Instantiate().Verbose(false);
+  Trainer *t = new Trainer;
+  t->nnet.Read(model);
+  return t;
+  CAPI_CATCH(NULL)
+}
+void nnet1_destroy(void *h) { delete static_cast<Trainer *>(h); }
+int nnet1_num_layers(void *h) { return static_cast<Trainer *>(h)->nnet.LayerCount(); }
+int nnet1_input_dim(void *h) {
+  CAPI_TRY
+  return static_cast<Trainer *>(h)->nnet.InputDim();
+  CAPI_CATCH(-1)
+}
+int nnet1_output_dim(void *h) {
+  CAPI_TRY
+  return static_cast<Trainer *>(h)->nnet.OutputDim();
+  CAPI_CATCH(-1)
+}
+
+int nnet1_set_train_opts(void *h, float learn_rate, float momentum, float l2_penalty, float l1_penalty,
+                         float l2_upper_bound, int average_grad, int fused, const char *learn_factors) {
+  CAPI_TRY
+  Nnet &n = static_cast<Trainer *>(h)->nnet;
+  n.SetLearnRate(learn_rate, (learn_factors && *learn_factors) ? learn_factors : NULL);
+  n.SetMomentum(momentum);
+  n.SetL2Penalty(l2_penalty);
+  n.SetL2UpperBound(l2_upper_bound);
+  n.SetL1Penalty(l1_penalty);
+  n.SetAverageGrad(average_grad != 0);
+  n.SetFusion(fused != 0);
+  return 0;
+  CAPI_CATCH(-1)
+}
+
+int nnet1_set_data_parallel(void *h, int nranks) {
+  CAPI_TRY
+  static_cast<Trainer *>(h)->nnet.SetDataParallel(nranks);
+  return 0;
+  CAPI_CATCH(-1)
+}
+
+int nnet1_train_bunch(void *h, const float *feats_dev, int ld, int rows, int cols, const int32_t *labels_dev,
+                      int cross_validate) {
+  CAPI_TRY
+  Trainer *t = static_cast<Trainer *>(h);
+  CopyIn(feats_dev, ld, rows, cols, &t->nnet_in);
+  t->targets.Resize(rows);
+  CU_SAFE_CALL(hipK_memcpy(CuDevice::Instantiate().Stream(), t->targets.Data(), labels_dev, rows * sizeof(int32), 2));
+  t->nnet.Propagate(t->nnet_in, &t->nnet_out);
+  t->xent.EvalVec(t->nnet_out, t->targets, &t->glob_err);
+  if (!cross_validate) t->nnet.Backpropagate(t->glob_err, NULL);
+  return 0;
+  CAPI_CATCH(-1)
+}
+
+int nnet1_feedforward(void *h, const float *feats_dev, int ld, int rows, int cols, float *out_dev, int ld_out) {
+  CAPI_TRY
+  Trainer *t = static_cast<Trainer *>(h);
+  CopyIn(feats_dev, ld, rows, cols, &t->nnet_in);
+  t->nnet.Feedforward(t->nnet_in, &t->nnet_out);
+  CU_SAFE_CALL(hipK_memcpy_2d(CuDevice::Instantiate().Stream(), out_dev, ld_out * sizeof(float), t->nnet_out.Data(),
+                              t->nnet_out.Stride() * sizeof(float), t->nnet_out.NumCols() * sizeof(float),
+                              t->nnet_out.NumRows(), 2));
+  return 0;
+  CAPI_CATCH(-1)
+}
+
+int nnet1_get_stats(void *h, long long *frames, long long *correct, double *loss) {
+  CAPI_TRY
+  int64 f, c;
+  double l;
+  static_cast<Trainer *>(h)->xent.GetStats(&f, &c, &l);
+  if (frames) *frames = f;
+  if (correct) *correct = c;
+  if (loss) *loss = l;
+  return 0;
+  CAPI_CATCH(-1)
+}
+int nnet1_reset_stats(void *h) {
+  CAPI_TRY
+  static_cast<Trainer *>(h)->xent.Reset();
+  return 0;
+  CAPI_CATCH(-1)
+}
+int nnet1_write(void *h, const char *wx, int binary) {
+  CAPI_TRY
+  static_cast<Trainer *>(h)->nnet.Write(wx, binary != 0);
+  return 0;
+  CAPI_CATCH(-1)
+}
+int nnet1_get_posteriors(void *h, float *host, int rows, int cols) {
+  CAPI_TRY
+  Trainer *t = static_cast<Trainer *>(h);
+  // after EvalVec the posteriors live in nnet_out (glob_err holds posterior - target)
+  if (t->nnet_out.NumRows() != rows || t->nnet_out.NumCols() != cols) KALDI_ERR << "shape mismatch";
+  Matrix<BaseFloat> m;
+  t->nnet_out.CopyToMat(&m);
+  memcpy(host, m.Data(), sizeof(float) * rows * cols);
+  return 0;
+  CAPI_CATCH(-1)
+}
+int nnet1_get_layer_params(void *h, int layer, float *w, float *b) {
+  CAPI_TRY
+  Trainer *t = static_cast<Trainer *>(h);
+  if (layer < 0 || layer >= t->nnet.LayerCount() || t->nnet.Layer(layer)->GetType() != Component::kBiasedLinearity)
+    KALDI_ERR << "layer " << layer << " is not a <biasedlinearity>";
+  BiasedLinearity *bl = static_cast<BiasedLinearity *>(t->nnet.Layer(layer));
+  Matrix<BaseFloat> m;
+  bl->GetLinearityWeight().CopyToMat(&m);
+  memcpy(w, m.Data(), sizeof(float) * m.NumRows() * m.NumCols());
+  Vector<BaseFloat> v;
+  bl->GetBiasWeight().CopyToVec(&v);
+  memcpy(b, v.Data(), sizeof(float) * v.Dim());
+  return 0;
+  CAPI_CATCH(-1)
+}
+
+void *rbm1_create(const char *model) {
+  CAPI_TRY
+  CuDevice::Instantiate().Verbose(false);
+  RbmTrainer *t = new RbmTrainer;
+  t->nnet.Read(model);
+  if (t->nnet.LayerCount() != 1 || t->nnet.Layer(0)->GetType() != Component::kRbm) {
+    delete t;
+    KALDI_ERR << "rbm1_create: the model must be exactly one <rbm>";
+  }
+  return t;
+  CAPI_CATCH(NULL)
+}
+void rbm1_destroy(void *h) { delete static_cast<RbmTrainer *>(h); }
+int rbm1_set_train_opts(void *h, float learn_rate, float momentum, float l2_penalty) {
+  CAPI_TRY
+  RbmBase &rbm = dynamic_cast<RbmBase &>(*static_cast<RbmTrainer *>(h)->nnet.Layer(0));
+  rbm.SetLearnRate(learn_rate);
+  rbm.SetMomentum(momentum);
+  rbm.SetL2Penalty(l2_penalty);
+  return 0;
+  CAPI_CATCH(-1)
+}
+int rbm1_cd1_bunch(void *h, const float *feats_dev, int ld, int rows, int cols) {
+  CAPI_TRY
+  RbmTrainer *t = static_cast<RbmTrainer *>(h);
+  RbmBase &rbm = dynamic_cast<RbmBase &>(*t->nnet.Layer(0));
+  CopyIn(feats_dev, ld, rows, cols, &t->pos_vis);
+  rbm.Propagate(t->pos_vis, &t->pos_hid);
+  if (rbm.HidType() == Rbm::BERNOULLI) {
+    t->cu_rand.BinarizeProbs(t->pos_hid, &t->neg_hid);
+  } else {
+    t->neg_hid.CopyFromMat(t->pos_hid);
+    t->cu_rand.AddGaussNoise(&t->neg_hid);
+  }
+  rbm.Reconstruct(t->neg_hid, &t->neg_vis);
+  rbm.Propagate(t->neg_vis, &t->neg_hid);
+  rbm.RbmUpdate(t->pos_vis, t->pos_hid, t->neg_vis, t->neg_hid);
+  t->mse.Eval(t->neg_vis, t->pos_vis, &t->dummy);
+  return 0;
+  CAPI_CATCH(-1)
+}
+int rbm1_write(void *h, const char *wx, int binary) {
+  CAPI_TRY
+  static_cast<RbmTrainer *>(h)->nnet.Write(wx, binary != 0);
+  return 0;
+  CAPI_CATCH(-1)
+}
+int rbm1_dims(void *h, int *vis, int *hid) {
+  CAPI_TRY
+  Nnet &n = static_cast<RbmTrainer *>(h)->nnet;
+  if (vis) *vis = n.InputDim();
+  if (hid) *hid = n.OutputDim();
+  return 0;
+  CAPI_CATCH(-1)
+}
+int nnet1_synchronize(void) {
+  CAPI_TRY
+  CuDevice::Instantiate().Synchronize();
+  return 0;
+  CAPI_CATCH(-1)
+}
+
+}  // extern "C"

@@ -71,14 +71,14 @@ KH_EXPORT int hipK_comm_rank(int *rank, int *nranks) {
 }
 
 template <typename T>
-static int allreduce(khStream_t s, T *buf, size_t count, ncclDataType_t dt) {
+static int allreduce(khStream_t s, T *buf, size_t count, ncclDataType_t dt, ncclRedOp_t op = ncclSum) {
   KH_CHECK_INIT();
   if (count == 0) return KH_OK;
   KH_REQUIRE(buf != nullptr);
   Comm &c = comm();
   if (c.nranks == 1) return KH_OK;  // a single replica already holds the sum
   if (!c.comm) return KH_ERR_NOT_INITIALISED;
-  KH_NCCL(ncclAllReduce(buf, buf, count, dt, ncclSum, c.comm, kh::pick(s)));
+  KH_NCCL(ncclAllReduce(buf, buf, count, dt, op, c.comm, kh::pick(s)));
   return KH_OK;
 }
 
@@ -90,6 +90,11 @@ KH_EXPORT int hipK_allreduce_sum_f64(khStream_t s, double *buf, size_t count) {
 }
 KH_EXPORT int hipK_allreduce_sum_i64(khStream_t s, long long *buf, size_t count) {
   return allreduce<long long>(s, buf, count, ncclInt64);
+}
+
+KH_EXPORT int hipK_allreduce_i64(khStream_t s, long long *buf, size_t count, int op) {
+  KH_REQUIRE(op >= 0 && op <= 2);
+  return allreduce<long long>(s, buf, count, ncclInt64, op == 0 ? ncclSum : op == 1 ? ncclMin : ncclMax);
 }
 
 KH_EXPORT int hipK_comm_barrier(khStream_t s) {

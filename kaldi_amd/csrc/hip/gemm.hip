@@ -537,7 +537,78 @@ __global__ __launch_bounds__(1024) void rbm_bias_kernel(const float *pos, int ld
   }
 }
 
+// element-wise second half of the data-parallel update (same formulas as the EPI_UPDATE epilogue)
+template <int VEC>
+__global__ __launch_bounds__(256) void affine_apply_kernel(int O, int I, const float *grad, int ldg, float g,
+                                                           float mom, float lr, float l2, float *W, int ldw,
+                                                           float *corr, int ldcorr) {
+  const int c = (blockIdx.x * 256 + threadIdx.x) * VEC;
+  if (c >= I) return;
+  for (int r = blockIdx.y; r < O; r += gridDim.y) {
+    float gv[VEC], cv[VEC], wv[VEC];
+    if (VEC == 4) {
+      *reinterpret_cast<float4 *>(gv) = *reinterpret_cast<const float4 *>(grad + (size_t)r * ldg + c);
+      *reinterpret_cast<float4 *>(wv) = *reinterpret_cast<const float4 *>(W + (size_t)r * ldw + c);
+      if (mom != 0.f) *reinterpret_cast<float4 *>(cv) = *reinterpret_cast<const float4 *>(corr + (size_t)r * ldcorr + c);
+    } else {
+      gv[0] = grad[(size_t)r * ldg + c];
+      wv[0] = W[(size_t)r * ldw + c];
+      if (mom != 0.f) cv[0] = corr[(size_t)r * ldcorr + c];
+    }
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      float cc = g * gv[i];
+      if (mom != 0.f) cc += mom * cv[i];
+      cv[i] = cc;
+      float w = wv[i];
+      if (l2 != 0.f) w = -l2 * w + w;
+      wv[i] = -lr * cc + w;
+    }
+    if (VEC == 4) {
+      *reinterpret_cast<float4 *>(W + (size_t)r * ldw + c) = *reinterpret_cast<float4 *>(wv);
+      if (corr) *reinterpret_cast<float4 *>(corr + (size_t)r * ldcorr + c) = *reinterpret_cast<float4 *>(cv);
+    } else {
+      W[(size_t)r * ldw + c] = wv[0];
+      if (corr) corr[(size_t)r * ldcorr + c] = cv[0];
+    }
+  }
+}
+
+__global__ void bias_apply_kernel(int O, const float *bgrad, float g, float mom, float lr, float *bias, float *bcorr) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= O) return;
+  float bc = g * bgrad[c];
+  if (mom != 0.f) bc += mom * bcorr[c];
+  if (bcorr) bcorr[c] = bc;
+  bias[c] = -lr * bc + bias[c];
+}
+
 }  // namespace
+
+KH_EXPORT int hipF_affine_apply(khStream_t s, int32_t O, int32_t I, const float *grad, int32_t ldg, const float *bgrad,
+                                float gscale, float momentum, float lr, float l2, float *W, int32_t ldw, float *corr,
+                                int32_t ldcorr, float *bias, float *bcorr) {
+  KH_CHECK_INIT();
+  KH_REQUIRE(O > 0 && I > 0 && grad && bgrad && W && bias && ldg >= I && ldw >= I);
+  KH_REQUIRE(momentum == 0.f || (corr != nullptr && bcorr != nullptr));
+  KH_REQUIRE(corr == nullptr || ldcorr >= I);
+  const bool vec = (I % 4 == 0) && (ldg % 4 == 0) && (ldw % 4 == 0) && (!corr || ldcorr % 4 == 0) &&
+                   kh::aligned16(grad) && kh::aligned16(W) && (!corr || kh::aligned16(corr));
+  const int per = vec ? 4 : 1;
+  int gx = (I + 256 * per - 1) / (256 * per), gy = O;
+  const int cap = 8192 / gx;
+  if (gy > cap) gy = cap < 1 ? 1 : cap;
+  hipStream_t st = kh::pick(s);
+  if (vec)
+    hipLaunchKernelGGL((affine_apply_kernel<4>), dim3(gx, gy), dim3(256), 0, st, O, I, grad, ldg, gscale, momentum, lr,
+                       l2, W, ldw, corr, ldcorr);
+  else
+    hipLaunchKernelGGL((affine_apply_kernel<1>), dim3(gx, gy), dim3(256), 0, st, O, I, grad, ldg, gscale, momentum, lr,
+                       l2, W, ldw, corr, ldcorr);
+  hipLaunchKernelGGL(bias_apply_kernel, dim3((O + 255) / 256), dim3(256), 0, st, O, bgrad, gscale, momentum, lr, bias,
+                     bcorr);
+  return kh::launch_status();
+}
 
 KH_EXPORT int hipF_gemm(khStream_t s, int transA, int transB, int32_t M, int32_t N, int32_t K, float alpha,
                         const float *A, int32_t lda, const float *B, int32_t ldb, float beta, float *C, int32_t ldc) {

@@ -242,6 +242,36 @@ KH_EXPORT int hipK_memcpy(khStream_t s, void *dst, const void *src, size_t bytes
   return KH_OK;
 }
 
+KH_EXPORT int hipK_event_create(khEvent_t *ev) {
+  KH_CHECK_INIT();
+  KH_REQUIRE(ev != nullptr);
+  hipEvent_t e;
+  KH_HIP(hipEventCreate(&e));
+  *ev = (khEvent_t)e;
+  return KH_OK;
+}
+KH_EXPORT int hipK_event_destroy(khEvent_t ev) {
+  if (!ev) return KH_OK;
+  KH_HIP(hipEventDestroy((hipEvent_t)ev));
+  return KH_OK;
+}
+KH_EXPORT int hipK_event_record(khEvent_t ev, khStream_t s) {
+  KH_CHECK_INIT();
+  KH_REQUIRE(ev != nullptr);
+  KH_HIP(hipEventRecord((hipEvent_t)ev, kh::pick(s)));
+  return KH_OK;
+}
+KH_EXPORT int hipK_event_synchronize(khEvent_t ev) {
+  KH_REQUIRE(ev != nullptr);
+  KH_HIP(hipEventSynchronize((hipEvent_t)ev));
+  return KH_OK;
+}
+KH_EXPORT int hipK_event_elapsed_ms(float *ms, khEvent_t start, khEvent_t stop) {
+  KH_REQUIRE(ms && start && stop);
+  KH_HIP(hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop));
+  return KH_OK;
+}
+
 KH_EXPORT int hipK_reserve_workspace(size_t bytes) {
   KH_CHECK_INIT();
   void *p;

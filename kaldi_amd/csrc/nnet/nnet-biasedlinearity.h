@@ -1,0 +1,166 @@
+// <biasedlinearity>: out = in * W^T + b.  Public interface of the reference's BiasedLinearity
+// (nnet/nnet-biasedlinearity.h:26-157) with the same update rule (:71-102); on the device the
+// bias add, the activation that follows, the sigmoid derivative of the layer below and the SGD
+// weight pass ride in the epilogues of the three GEMMs.
+#ifndef KALDI_AMD_NNET_NNET_BIASEDLINEARITY_H_
+#define KALDI_AMD_NNET_NNET_BIASEDLINEARITY_H_
+#include "cudamatrix/cu-math.h"
+#include "nnet/nnet-component.h"
+
+namespace kaldi {
+
+class BiasedLinearity : public UpdatableComponent {
+ public:
+  BiasedLinearity(MatrixIndexT dim_in, MatrixIndexT dim_out, Nnet *nnet)
+      : UpdatableComponent(dim_in, dim_out, nnet),
+        linearity_(dim_out, dim_in), bias_(dim_out), linearity_corr_(dim_out, dim_in), bias_corr_(dim_out) {}
+  ~BiasedLinearity() {}
+
+  ComponentType GetType() const { return kBiasedLinearity; }
+
+  void ReadData(std::istream &is, bool binary) {
+    linearity_.Read(is, binary);
+    bias_.Read(is, binary);
+    KALDI_ASSERT(linearity_.NumRows() == output_dim_);
+    KALDI_ASSERT(linearity_.NumCols() == input_dim_);
+    KALDI_ASSERT(static_cast<MatrixIndexT>(bias_.Dim()) == output_dim_);
+  }
+  void WriteData(std::ostream &os, bool binary) const {
+    linearity_.Write(os, binary);
+    bias_.Write(os, binary);
+  }
+
+  void PropagateFnc(const CuMatrix<BaseFloat> &in, CuMatrix<BaseFloat> *out) { Forward(in, KH_ACT_NONE, out); }
+
+  void BackpropagateFnc(const CuMatrix<BaseFloat> &in_err, CuMatrix<BaseFloat> *out_err) {
+    CuProfileScope p("BiasedLinearity::Backpropagate");
+    CU_SAFE_CALL(hipF_affine_backward(S(), in_err.NumRows(), output_dim_, input_dim_, in_err.Data(), in_err.Stride(),
+                                      linearity_.Data(), linearity_.Stride(), NULL, 0, out_err->Data(), out_err->Stride()));
+  }
+
+  /// out = act(in * W^T + b), act = KH_ACT_NONE | KH_ACT_SIGMOID | KH_ACT_SOFTMAX, one pass
+  void PropagateFused(const CuMatrix<BaseFloat> &in, int act, CuMatrix<BaseFloat> *out) {
+    if (input_dim_ != in.NumCols()) KALDI_ERR << "Nonmatching dims, component:" << input_dim_ << " data:" << in.NumCols();
+    if (output_dim_ != out->NumCols() || in.NumRows() != out->NumRows()) out->Resize(in.NumRows(), output_dim_);
+    Forward(in, act, out);
+  }
+  /// out_err = (in_err * W) .* y .* (1-y): this layer's backprop followed by that of the sigmoid
+  /// that produced this layer's input y
+  void BackpropagateFused(const CuMatrix<BaseFloat> &in_err, const CuMatrix<BaseFloat> &y, CuMatrix<BaseFloat> *out_err) {
+    CuProfileScope p("BiasedLinearity::BackpropagateFused");
+    if (output_dim_ != in_err.NumCols())
+      KALDI_ERR << "Nonmatching dims, component:" << output_dim_ << " data:" << in_err.NumCols();
+    KALDI_ASSERT(y.NumCols() == input_dim_ && y.NumRows() == in_err.NumRows());
+    if (input_dim_ != out_err->NumCols() || in_err.NumRows() != out_err->NumRows())
+      out_err->Resize(in_err.NumRows(), input_dim_);
+    CU_SAFE_CALL(hipF_affine_backward(S(), in_err.NumRows(), output_dim_, input_dim_, in_err.Data(), in_err.Stride(),
+                                      linearity_.Data(), linearity_.Stride(), y.Data(), y.Stride(), out_err->Data(),
+                                      out_err->Stride()));
+  }
+
+  void Update(const CuMatrix<BaseFloat> &input, const CuMatrix<BaseFloat> &err) {
+    CuProfileScope p("BiasedLinearity::Update");
+    const int32 n = input.NumRows();
+    KALDI_ASSERT(err.NumRows() == n && err.NumCols() == output_dim_ && input.NumCols() == input_dim_);
+    const BaseFloat gscale = average_grad_ ? 1.0 / n : 1.0;
+    const BaseFloat l2 = (l2_penalty_ != 0.0) ? learn_rate_ * l2_penalty_ * n : 0.0;
+    if (l1_penalty_ == 0.0) {
+      // gradient GEMM with the momentum / weight-decay / SGD step in its epilogue
+      CU_SAFE_CALL(hipF_affine_update(S(), n, output_dim_, input_dim_, err.Data(), err.Stride(), input.Data(),
+                                      input.Stride(), gscale, momentum_, learn_rate_, l2, linearity_.Data(),
+                                      linearity_.Stride(), KeepCorr() ? linearity_corr_.Data() : NULL,
+                                      linearity_corr_.Stride(), bias_.Data(), KeepCorr() ? bias_corr_.Data() : NULL));
+    } else {
+      // the L1 shrink sits between the gradient and the step, so the passes stay separate
+      linearity_corr_.AddMatMat(gscale, err, kTrans, input, kNoTrans, momentum_);
+      bias_corr_.AddRowSumMat(gscale, err, momentum_);
+      if (l2 != 0.0) linearity_.AddMat(-l2, linearity_);
+      const BaseFloat l1 = learn_rate_ * n * l1_penalty_;
+      cu::RegularizeL1(&linearity_, &linearity_corr_, l1, learn_rate_);
+      linearity_.AddMat(-learn_rate_, linearity_corr_);
+      bias_.AddVec(-learn_rate_, bias_corr_);
+    }
+    if (l2_upper_bound_ > 0.0) linearity_.ApplyRowL2UpperBound(l2_upper_bound_);
+  }
+
+  /// Data-parallel form of Update, first half: the raw sums  gW = err^T * input  and
+  /// gb = colsum(err)  into one contiguous buffer [gW (dim_out x dim_in, dense) | gb].
+  void ComputeGradient(const CuMatrix<BaseFloat> &input, const CuMatrix<BaseFloat> &err, BaseFloat *grad_buf) {
+    CuProfileScope p("BiasedLinearity::ComputeGradient");
+    const int32 n = input.NumRows();
+    CU_SAFE_CALL(hipF_gemm(S(), KH_TRANS, KH_NO_TRANS, output_dim_, input_dim_, n, 1.0f, err.Data(), err.Stride(),
+                           input.Data(), input.Stride(), 0.0f, grad_buf, input_dim_));
+    CU_SAFE_CALL(hipF_add_row_sum_mat(S(), 1.0f, err.Data(), err.Dim(), 0.0f,
+                                      grad_buf + static_cast<size_t>(output_dim_) * input_dim_));
+  }
+  size_t GradientSize() const { return static_cast<size_t>(output_dim_) * input_dim_ + output_dim_; }
+  /// second half: momentum, weight decay and the step from the (all-reduced) sums over
+  /// total_frames frames
+  void ApplyGradient(const BaseFloat *grad_buf, int32 total_frames) {
+    CuProfileScope p("BiasedLinearity::ApplyGradient");
+    KALDI_ASSERT(l1_penalty_ == 0.0);
+    const BaseFloat gscale = average_grad_ ? 1.0 / total_frames : 1.0;
+    const BaseFloat l2 = (l2_penalty_ != 0.0) ? learn_rate_ * l2_penalty_ * total_frames : 0.0;
+    CU_SAFE_CALL(hipF_affine_apply(S(), output_dim_, input_dim_, grad_buf, input_dim_,
+                                   grad_buf + static_cast<size_t>(output_dim_) * input_dim_, gscale, momentum_,
+                                   learn_rate_, l2, linearity_.Data(), linearity_.Stride(),
+                                   KeepCorr() ? linearity_corr_.Data() : NULL, linearity_corr_.Stride(), bias_.Data(),
+                                   KeepCorr() ? bias_corr_.Data() : NULL));
+    if (l2_upper_bound_ > 0.0) linearity_.ApplyRowL2UpperBound(l2_upper_bound_);
+  }
+
+  void SetLinearityWeight(const CuMatrix<BaseFloat> &weight, bool trans) {
+    if (trans) {
+      Matrix<BaseFloat> mat;
+      weight.CopyToMat(&mat);
+      mat.Transpose();
+      linearity_.CopyFromMat(mat);
+    } else {
+      linearity_.CopyFromMat(weight);
+    }
+  }
+  void SetLinearityWeight(const Matrix<BaseFloat> &weight, bool trans) {
+    if (trans) {
+      Matrix<BaseFloat> mat(weight);
+      mat.Transpose();
+      linearity_.CopyFromMat(mat);
+    } else {
+      linearity_.CopyFromMat(weight);
+    }
+  }
+  const CuMatrix<BaseFloat> &GetLinearityWeight() { return linearity_; }
+  void SetBiasWeight(const CuVector<BaseFloat> &bias) { bias_.CopyFromVec(bias); }
+  void SetBiasWeight(const Vector<BaseFloat> &bias) { bias_.CopyFromVec(bias); }
+  const CuVector<BaseFloat> &GetBiasWeight() { return bias_; }
+  /// Momentum state (zero after construction; never written to disk).  With momentum 0 the
+  /// correction equals the current gradient and is only stored when asked for with
+  /// SetKeepGradient(true): nothing on the training path reads it and skipping the store saves
+  /// one full pass over the weight matrix per step.
+  const CuMatrix<BaseFloat> &GetLinearityCorr() { return linearity_corr_; }
+  const CuVector<BaseFloat> &GetBiasCorr() { return bias_corr_; }
+  void SetKeepGradient(bool keep) { keep_gradient_ = keep; }
+  void SetToIdentity() {
+    Matrix<BaseFloat> mat(linearity_.NumRows(), linearity_.NumCols());
+    mat.SetUnit();
+    linearity_.CopyFromMat(mat);
+    bias_.SetZero();
+  }
+
+ protected:
+  static khStream_t S() { return CuDevice::Instantiate().Stream(); }
+  bool KeepCorr() const { return momentum_ != 0.0 || keep_gradient_; }
+  void Forward(const CuMatrix<BaseFloat> &in, int act, CuMatrix<BaseFloat> *out) {
+    CuProfileScope p("BiasedLinearity::Propagate");
+    CU_SAFE_CALL(hipF_affine_forward(S(), act, KH_TRANS, in.NumRows(), output_dim_, input_dim_, in.Data(), in.Stride(),
+                                     linearity_.Data(), linearity_.Stride(), bias_.Data(), out->Data(), out->Stride()));
+  }
+
+  CuMatrix<BaseFloat> linearity_;
+  CuVector<BaseFloat> bias_;
+  CuMatrix<BaseFloat> linearity_corr_;
+  CuVector<BaseFloat> bias_corr_;
+  bool keep_gradient_ = false;
+};
+
+}  // namespace kaldi
+#endif

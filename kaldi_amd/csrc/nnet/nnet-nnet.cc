@@ -1,0 +1,260 @@
+#include "nnet/nnet-nnet.h"
+
+#include <stdlib.h>
+#include <string.h>
+
+#include "nnet/nnet-activation.h"
+#include "nnet/nnet-biasedlinearity.h"
+#include "nnet/nnet-various.h"
+
+namespace kaldi {
+
+Nnet::~Nnet() {
+  for (size_t i = 0; i < nnet_.size(); ++i) delete nnet_[i];
+  if (dp_grad_) hipK_free(dp_grad_);
+}
+
+MatrixIndexT Nnet::InputDim() const {
+  if (LayerCount() == 0) KALDI_ERR << "No layers in MLP";
+  return nnet_.front()->InputDim();
+}
+
+MatrixIndexT Nnet::OutputDim() const {
+  if (LayerCount() == 0) KALDI_ERR << "No layers in MLP";
+  return nnet_.back()->OutputDim();
+}
+
+int32 Nnet::IndexOfLayer(const Component &comp) const {
+  for (int32 i = 0; i < LayerCount(); ++i)
+    if (&comp == nnet_[i]) return i;
+  KALDI_ERR << "Component:" << &comp << " type:" << comp.GetType() << " not found in the MLP";
+  return -1;
+}
+
+static inline int ActivationAfter(const std::vector<Component *> &net, int32 i) {
+  if (i + 1 >= static_cast<int32>(net.size())) return -1;
+  if (net[i]->GetType() != Component::kBiasedLinearity) return -1;
+  if (net[i + 1]->InputDim() != net[i + 1]->OutputDim()) return -1;
+  if (net[i + 1]->GetType() == Component::kSigmoid) return KH_ACT_SIGMOID;
+  if (net[i + 1]->GetType() == Component::kSoftmax) return KH_ACT_SOFTMAX;
+  return -1;
+}
+
+void Nnet::Propagate(const CuMatrix<BaseFloat> &in, CuMatrix<BaseFloat> *out) {
+  KALDI_ASSERT(NULL != out);
+  const int32 L = LayerCount();
+  if (L == 0) {
+    out->CopyFromMat(in);
+    return;
+  }
+  KALDI_ASSERT(static_cast<int32>(propagate_buf_.size()) >= L + 1);
+  propagate_buf_[0].CopyFromMat(in);
+  for (int32 i = 0; i < L; ++i) {
+    const int act = fusion_ ? ActivationAfter(nnet_, i) : -1;
+    if (act >= 0) {
+      static_cast<BiasedLinearity *>(nnet_[i])->PropagateFused(propagate_buf_[i], act, &propagate_buf_[i + 2]);
+      ++i;  // the activation has been applied
+    } else {
+      nnet_[i]->Propagate(propagate_buf_[i], &propagate_buf_[i + 1]);
+    }
+  }
+  CuMatrix<BaseFloat> &last = propagate_buf_[L];
+  if (fusion_ && nnet_[L - 1]->GetType() == Component::kSoftmax && out->NumRows() == last.NumRows() &&
+      out->NumCols() == last.NumCols()) {
+    // Nothing reads the softmax output from the buffers during backprop (its Backpropagate only
+    // forwards the error), so the result is handed over by exchanging the two allocations.
+    out->Swap(&last);
+  } else {
+    out->CopyFromMat(last);
+  }
+}
+
+void Nnet::UpdateLayer(int32 i, const CuMatrix<BaseFloat> &input, const CuMatrix<BaseFloat> &err) {
+  if (!nnet_[i]->IsUpdatable()) return;
+  UpdatableComponent *uc = dynamic_cast<UpdatableComponent *>(nnet_[i]);
+  if (!(uc->GetLearnRate() > 0.0)) return;
+  if (dp_ranks_ > 1) {
+    if (nnet_[i]->GetType() != Component::kBiasedLinearity)
+      KALDI_ERR << "Data-parallel training supports <biasedlinearity> layers only";
+    BiasedLinearity *bl = static_cast<BiasedLinearity *>(nnet_[i]);
+    const size_t need = bl->GradientSize();
+    if (need > dp_grad_size_) {
+      if (dp_grad_) {
+        CuDevice::Instantiate().Synchronize();
+        CU_SAFE_CALL(hipK_free(dp_grad_));
+      }
+      void *p = NULL;
+      CU_SAFE_CALL(hipK_malloc(&p, need * sizeof(BaseFloat)));
+      dp_grad_ = static_cast<BaseFloat *>(p);
+      dp_grad_size_ = need;
+    }
+    bl->ComputeGradient(input, err, dp_grad_);
+    CU_SAFE_CALL(hipF_allreduce_sum(CuDevice::Instantiate().Stream(), dp_grad_, need));
+    bl->ApplyGradient(dp_grad_, input.NumRows() * dp_ranks_);
+  } else {
+    uc->Update(input, err);
+  }
+}
+
+void Nnet::Backpropagate(const CuMatrix<BaseFloat> &in_err, CuMatrix<BaseFloat> *out_err) {
+  const int32 L = LayerCount();
+  if (L == 0) KALDI_ERR << "Cannot backpropagate on empty network";
+  KALDI_ASSERT(static_cast<int32>(propagate_buf_.size()) >= L + 1);
+  KALDI_ASSERT(static_cast<int32>(backpropagate_buf_.size()) >= L - 1);
+
+  const CuMatrix<BaseFloat> *err = &in_err;  // error w.r.t. the output of layer i
+  int32 i = L - 1;
+  while (i >= 0) {
+    Component *comp = nnet_[i];
+    // where the error w.r.t. this layer's input goes (NULL: nobody wants it)
+    CuMatrix<BaseFloat> *below = (i > 0) ? &backpropagate_buf_[i - 1] : out_err;
+
+    if (fusion_ && comp->GetType() == Component::kSoftmax && i > 0 && comp->InputDim() == comp->OutputDim()) {
+      --i;  // identity on the error
+      continue;
+    }
+    if (fusion_ && comp->GetType() == Component::kBiasedLinearity && i >= 1 &&
+        nnet_[i - 1]->GetType() == Component::kSigmoid && nnet_[i - 1]->InputDim() == nnet_[i - 1]->OutputDim()) {
+      // this layer and the sigmoid below it in one step; y = propagate_buf_[i] is that sigmoid's output
+      BiasedLinearity *bl = static_cast<BiasedLinearity *>(comp);
+      CuMatrix<BaseFloat> *below2 = (i - 1 > 0) ? &backpropagate_buf_[i - 2] : out_err;
+      if (below2 != NULL) bl->BackpropagateFused(*err, propagate_buf_[i], below2);
+      UpdateLayer(i, propagate_buf_[i], *err);
+      err = below2;
+      i -= 2;
+      continue;
+    }
+    if (below != NULL) comp->Backpropagate(*err, below);
+    UpdateLayer(i, propagate_buf_[i], *err);
+    err = below;
+    --i;
+  }
+}
+
+void Nnet::Feedforward(const CuMatrix<BaseFloat> &in, CuMatrix<BaseFloat> *out) {
+  KALDI_ASSERT(NULL != out);
+  const int32 L = LayerCount();
+  if (L == 0) {
+    out->CopyFromMat(in);
+    return;
+  }
+  KALDI_ASSERT(propagate_buf_.size() >= 2 || L == 1);
+  // steps: each is one component or a fused (linearity, activation) pair; intermediate results
+  // alternate between the first two buffers, the last step writes into *out
+  const CuMatrix<BaseFloat> *src = &in;
+  int32 flip = 0;
+  for (int32 i = 0; i < L;) {
+    const int act = fusion_ ? ActivationAfter(nnet_, i) : -1;
+    const int32 next = i + (act >= 0 ? 2 : 1);
+    CuMatrix<BaseFloat> *dst = (next >= L) ? out : &propagate_buf_[flip];
+    if (act >= 0) static_cast<BiasedLinearity *>(nnet_[i])->PropagateFused(*src, act, dst);
+    else nnet_[i]->Propagate(*src, dst);
+    src = dst;
+    flip ^= 1;
+    i = next;
+  }
+}
+
+void Nnet::Read(const std::string &file) {
+  bool binary;
+  Input in(file, &binary);
+  Read(in.Stream(), binary);
+  in.Close();
+}
+
+void Nnet::Read(std::istream &in, bool binary) {
+  Component *comp;
+  while (NULL != (comp = Component::Read(in, binary, this))) {
+    if (LayerCount() > 0 && nnet_.back()->OutputDim() != comp->InputDim()) {
+      KALDI_ERR << "Dimensionality mismatch!"
+                << " Previous layer output:" << nnet_.back()->OutputDim() << " Current layer input:" << comp->InputDim();
+    }
+    nnet_.push_back(comp);
+  }
+  propagate_buf_.resize(LayerCount() + 1);
+  backpropagate_buf_.resize(LayerCount() > 0 ? LayerCount() - 1 : 0);
+  learn_rate_ = 0.0;
+}
+
+void Nnet::Write(const std::string &file, bool binary) {
+  Output out(file, binary, true);
+  Write(out.Stream(), binary);
+  out.Close();
+}
+
+void Nnet::Write(std::ostream &out, bool binary) {
+  for (int32 i = 0; i < LayerCount(); ++i) nnet_[i]->Write(out, binary);
+}
+
+void Nnet::WriteFrontLayers(std::ostream &out, bool binary, int32 num_layers) {
+  KALDI_ASSERT(num_layers <= LayerCount());
+  for (int32 i = 0; i < num_layers; ++i) nnet_[i]->Write(out, binary);
+}
+
+void Nnet::SetLearnRate(BaseFloat lrate, const char *lrate_factors) {
+  std::vector<BaseFloat> factors;
+  if (NULL != lrate_factors) {
+    std::string s(lrate_factors);
+    size_t pos = 0;
+    while ((pos = s.find_first_not_of(",:; ", pos)) != std::string::npos) {
+      const size_t end = s.find_first_of(",:; ", pos);
+      factors.push_back(atof(s.substr(pos, end == std::string::npos ? std::string::npos : end - pos).c_str()));
+      if (end == std::string::npos) break;
+      pos = end;
+    }
+  }
+  int32 updatable = 0;
+  for (int32 i = 0; i < LayerCount(); ++i)
+    if (nnet_[i]->IsUpdatable()) ++updatable;
+  if (!factors.empty() && updatable != static_cast<int32>(factors.size()))
+    KALDI_ERR << "Mismatch between number of trainable layers " << updatable << " and learn rate factors "
+              << factors.size();
+  int32 k = 0;
+  for (int32 i = 0; i < LayerCount(); ++i) {
+    if (!nnet_[i]->IsUpdatable()) continue;
+    BaseFloat scaled = lrate;
+    if (!factors.empty()) scaled *= factors[k++];
+    dynamic_cast<UpdatableComponent *>(nnet_[i])->SetLearnRate(scaled);
+  }
+  learn_rate_ = lrate;
+}
+
+std::string Nnet::GetLearnRateString() {
+  std::ostringstream oss;
+  oss << "LEARN_RATE global: " << learn_rate_ << " individual: ";
+  for (int32 i = 0; i < LayerCount(); ++i)
+    if (nnet_[i]->IsUpdatable()) oss << dynamic_cast<UpdatableComponent *>(nnet_[i])->GetLearnRate() << " ";
+  return oss.str();
+}
+
+#define KALDI_AMD_FOR_UPDATABLE(call)                                                  \
+  for (int32 i = 0; i < LayerCount(); ++i)                                             \
+    if (nnet_[i]->IsUpdatable()) dynamic_cast<UpdatableComponent *>(nnet_[i])->call
+
+void Nnet::SetMomentum(BaseFloat mmt) { KALDI_AMD_FOR_UPDATABLE(SetMomentum(mmt)); }
+void Nnet::SetL2Penalty(BaseFloat l2) { KALDI_AMD_FOR_UPDATABLE(SetL2Penalty(l2)); }
+void Nnet::SetL2UpperBound(BaseFloat bound) { KALDI_AMD_FOR_UPDATABLE(SetL2UpperBound(bound)); }
+void Nnet::SetL1Penalty(BaseFloat l1) { KALDI_AMD_FOR_UPDATABLE(SetL1Penalty(l1)); }
+void Nnet::SetAverageGrad(bool flag) { KALDI_AMD_FOR_UPDATABLE(SetAverageGrad(flag)); }
+#undef KALDI_AMD_FOR_UPDATABLE
+
+void Nnet::SetDataParallel(int32 nranks) {
+  KALDI_ASSERT(nranks >= 1);
+  dp_ranks_ = nranks;
+}
+
+// ---- activations that look their buffers up in the owning network ------------------------------
+void Sigmoid::BackpropagateFnc(const CuMatrix<BaseFloat> &in_err, CuMatrix<BaseFloat> *out_err) {
+  const CuMatrix<BaseFloat> &y = nnet_->PropagateBuffer()[nnet_->IndexOfLayer(*this) + 1];
+  cu::DiffSigmoid(in_err, y, out_err);
+}
+void Relu::BackpropagateFnc(const CuMatrix<BaseFloat> &in_err, CuMatrix<BaseFloat> *out_err) {
+  const CuMatrix<BaseFloat> &y = nnet_->PropagateBuffer()[nnet_->IndexOfLayer(*this) + 1];
+  cu::DiffRelu(in_err, y, out_err);
+}
+void SoftRelu::BackpropagateFnc(const CuMatrix<BaseFloat> &in_err, CuMatrix<BaseFloat> *out_err) {
+  const CuMatrix<BaseFloat> &x = nnet_->PropagateBuffer()[nnet_->IndexOfLayer(*this)];
+  cu::DiffSoftRelu(in_err, x, out_err);
+}
+
+}  // namespace kaldi

@@ -1,0 +1,87 @@
+// Nnet: an ordered list of Components plus the forward / backward buffers.  Public interface of
+// the reference's Nnet (nnet/nnet-nnet.h:36-111).
+//
+// Forward and backward passes recognise the sigmoid-DNN pattern of the hot path and run it fused
+// (SetFusion(false) restores one kernel per component):
+//   <biasedlinearity> + <sigmoid>|<softmax>  -> one GEMM whose epilogue adds the bias and applies
+//       the activation; the pre-activation buffer PropagateBuffer()[i+1] stays empty;
+//   backward through <biasedlinearity> preceded by <sigmoid> -> one GEMM whose epilogue multiplies
+//       by y(1-y); BackpropagateBuffer()[i-1] stays empty;
+//   <softmax> backward (a copy in the reference) -> no work, the error is used in place.
+// The order of operations that matters for the result is the reference's (nnet-nnet.cc:50-118):
+// per layer, top down, first back-propagate through the OLD weights, then update them.
+#ifndef KALDI_AMD_NNET_NNET_NNET_H_
+#define KALDI_AMD_NNET_NNET_NNET_H_
+#include <iostream>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "base/kaldi-common.h"
+#include "matrix/matrix-lib.h"
+#include "nnet/nnet-component.h"
+#include "util/kaldi-io.h"
+
+namespace kaldi {
+
+class Nnet {
+ public:
+  Nnet() : learn_rate_(0.0), fusion_(true), dp_ranks_(1), dp_grad_(NULL), dp_grad_size_(0) {}
+  ~Nnet();
+
+  /// forward pass, keeping every layer's output for Backpropagate
+  void Propagate(const CuMatrix<BaseFloat> &in, CuMatrix<BaseFloat> *out);
+  /// backward pass + parameter update; out_err == NULL skips the input gradient of layer 0
+  void Backpropagate(const CuMatrix<BaseFloat> &in_err, CuMatrix<BaseFloat> *out_err);
+  /// forward pass that keeps two ping-pong buffers only (inference)
+  void Feedforward(const CuMatrix<BaseFloat> &in, CuMatrix<BaseFloat> *out);
+
+  MatrixIndexT InputDim() const;
+  MatrixIndexT OutputDim() const;
+  MatrixIndexT LayerCount() const { return nnet_.size(); }
+  Component *Layer(MatrixIndexT index) { return nnet_[index]; }
+  int IndexOfLayer(const Component &comp) const;
+
+  const std::vector<CuMatrix<BaseFloat> > &PropagateBuffer() const { return propagate_buf_; }
+  const std::vector<CuMatrix<BaseFloat> > &BackpropagateBuffer() const { return backpropagate_buf_; }
+
+  void Read(const std::string &file);
+  void Read(std::istream &in, bool binary);
+  void Write(const std::string &file, bool binary);
+  void Write(std::ostream &out, bool binary);
+  void WriteFrontLayers(std::ostream &out, bool binary, int32 num_layers);
+
+  /// lrate_factors: optional per-updatable-layer multipliers separated by ",:; "
+  void SetLearnRate(BaseFloat lrate, const char *lrate_factors);
+  BaseFloat GetLearnRate() { return learn_rate_; }
+  std::string GetLearnRateString();
+  void SetMomentum(BaseFloat mmt);
+  void SetL2Penalty(BaseFloat l2);
+  void SetL2UpperBound(BaseFloat bound);
+  void SetL1Penalty(BaseFloat l1);
+  void SetAverageGrad(bool flag);
+
+  /// fused forward/backward for the sigmoid-DNN pattern (on by default)
+  void SetFusion(bool on) { fusion_ = on; }
+  /// Synchronous data-parallel training over `nranks` processes (one GPU each, communicator set up
+  /// with hipK_comm_init): every <biasedlinearity> update becomes gradient -> sum all-reduce ->
+  /// identical step on every rank, equal to one process training on the concatenated bunch.
+  void SetDataParallel(int32 nranks);
+
+ private:
+  typedef std::vector<Component *> NnetType;
+  void UpdateLayer(int32 i, const CuMatrix<BaseFloat> &input, const CuMatrix<BaseFloat> &err);
+
+  NnetType nnet_;
+  std::vector<CuMatrix<BaseFloat> > propagate_buf_;
+  std::vector<CuMatrix<BaseFloat> > backpropagate_buf_;
+  BaseFloat learn_rate_;
+  bool fusion_;
+  int32 dp_ranks_;
+  BaseFloat *dp_grad_;   // device staging buffer for one layer's gradient
+  size_t dp_grad_size_;
+  KALDI_DISALLOW_COPY_AND_ASSIGN(Nnet);
+};
+
+}  // namespace kaldi
+#endif

@@ -1,0 +1,126 @@
+// Multi-GPU plumbing shared by the nnetbin tools: one process per GPU, rank / world size from
+// the command line or the launcher's environment (RANK, WORLD_SIZE, LOCAL_RANK as set by
+// torch.distributed.run or mpirun-style wrappers), RCCL unique id exchanged through a file.
+// The reference tools are single-GPU; with one rank everything here is a no-op.
+#ifndef KALDI_AMD_NNETBIN_DIST_UTILS_H_
+#define KALDI_AMD_NNETBIN_DIST_UTILS_H_
+#include <stdio.h>
+#include <stdlib.h>
+#include <unistd.h>
+
+#include <fstream>
+#include <string>
+#include <vector>
+
+#include "cudamatrix/cu-device.h"
+#include "util/parse-options.h"
+
+namespace kaldi {
+
+struct DistOptions {
+  int32 num_ranks, rank, gpu_id;
+  std::string comm_id_file;
+  DistOptions() : num_ranks(0), rank(-1), gpu_id(-1) {}
+  void Register(ParseOptions *po) {
+    po->Register("num-ranks", &num_ranks, "Number of cooperating processes, one GPU each (0: take WORLD_SIZE, else 1)");
+    po->Register("rank", &rank, "Rank of this process (-1: take RANK, else 0)");
+    po->Register("gpu-id", &gpu_id, "GPU ordinal (-1: LOCAL_RANK when multi-rank, else the GPU with most free memory)");
+    po->Register("comm-id-file", &comm_id_file, "File through which rank 0 hands the RCCL unique id to the other ranks");
+  }
+  /// fills the unset fields from the environment
+  void Resolve() {
+    const char *e;
+    if (num_ranks <= 0) num_ranks = (e = getenv("WORLD_SIZE")) ? atoi(e) : 1;
+    if (rank < 0) rank = (e = getenv("RANK")) ? atoi(e) : 0;
+    if (num_ranks < 1 || rank < 0 || rank >= num_ranks) KALDI_ERR << "Invalid rank " << rank << " of " << num_ranks;
+    if (gpu_id < 0 && num_ranks > 1) gpu_id = (e = getenv("LOCAL_RANK")) ? atoi(e) : rank;
+    if (comm_id_file.empty() && num_ranks > 1) {
+      const char *port = getenv("MASTER_PORT");
+      comm_id_file = std::string("/tmp/kaldi_amd_comm_") + (port ? port : "default");
+    }
+  }
+};
+
+/// selects the GPU and, with more than one rank, builds the RCCL communicator
+inline void DistInit(const DistOptions &o) {
+  CuDevice::Instantiate().SelectGpuId(o.gpu_id);
+  if (o.num_ranks == 1) return;
+  unsigned char id[KH_COMM_ID_BYTES];
+  const std::string tmp = o.comm_id_file + ".tmp";
+  if (o.rank == 0) {
+    CU_SAFE_CALL(hipK_comm_get_unique_id(id));
+    std::ofstream os(tmp.c_str(), std::ios::binary);
+    os.write(reinterpret_cast<const char *>(id), sizeof(id));
+    os.close();
+    if (!os.good() || rename(tmp.c_str(), o.comm_id_file.c_str()) != 0)
+      KALDI_ERR << "Cannot write the communicator id to " << o.comm_id_file;
+  } else {
+    bool ok = false;
+    for (int tries = 0; tries < 6000 && !ok; ++tries) {  // up to 10 minutes
+      std::ifstream is(o.comm_id_file.c_str(), std::ios::binary);
+      if (is.good()) {
+        is.read(reinterpret_cast<char *>(id), sizeof(id));
+        ok = is.gcount() == static_cast<std::streamsize>(sizeof(id));
+      }
+      if (!ok) usleep(100000);
+    }
+    if (!ok) KALDI_ERR << "Timed out waiting for the communicator id in " << o.comm_id_file;
+  }
+  CU_SAFE_CALL(hipK_comm_init(id, o.rank, o.num_ranks));
+  CU_SAFE_CALL(hipK_comm_barrier(CuDevice::Instantiate().Stream()));
+  if (o.rank == 0) remove(o.comm_id_file.c_str());  // every rank has joined
+}
+
+inline void DistFinalize(const DistOptions &o) {
+  if (o.num_ranks > 1) CU_SAFE_CALL(hipK_comm_destroy());
+}
+
+/// all-reduce of one host integer (op 0 sum, 1 min, 2 max); blocking
+inline int64 DistAllReduce(const DistOptions &o, int64 value, int op) {
+  if (o.num_ranks == 1) return value;
+  static long long *dev = NULL;
+  if (!dev) {
+    void *p = NULL;
+    CU_SAFE_CALL(hipK_malloc(&p, sizeof(long long)));
+    dev = static_cast<long long *>(p);
+  }
+  khStream_t s = CuDevice::Instantiate().Stream();
+  long long v = value;
+  CU_SAFE_CALL(hipK_memcpy(s, dev, &v, sizeof(v), 0));
+  CU_SAFE_CALL(hipK_allreduce_i64(s, dev, 1, op));
+  CU_SAFE_CALL(hipK_memcpy(s, &v, dev, sizeof(v), 1));
+  return v;
+}
+
+/// Utterance -> rank assignment, evaluated identically by every rank while it streams through the
+/// same table: each utterance goes to the rank that has received the fewest frames so far (lowest
+/// rank on ties), which balances shards by frames rather than by utterance count.
+class ShardAssigner {
+ public:
+  explicit ShardAssigner(int32 num_ranks) : frames_(num_ranks, 0) {}
+  int32 Assign(int64 num_frames) {
+    int32 best = 0;
+    for (size_t r = 1; r < frames_.size(); ++r)
+      if (frames_[r] < frames_[best]) best = r;
+    frames_[best] += num_frames;
+    return best;
+  }
+
+ private:
+  std::vector<int64> frames_;
+};
+
+/// "ark:out.JOB.ark" -> "ark:out.3.ark" for rank 2, the JOB=1:N convention of the recipes
+inline std::string SubstituteJob(const std::string &s, int32 rank) {
+  std::string out = s;
+  const std::string job = std::to_string(rank + 1);
+  size_t pos = 0;
+  while ((pos = out.find("JOB", pos)) != std::string::npos) {
+    out.replace(pos, 3, job);
+    pos += job.size();
+  }
+  return out;
+}
+
+}  // namespace kaldi
+#endif

@@ -1,0 +1,131 @@
+// nnet-forward: forward pass of a network over a feature table.  Command line, options, NaN/inf
+// checks, log lines and exit status of the reference tool (nnetbin/nnet-forward.cc:27-182); with
+// --num-ranks > 1 the utterances are sharded over the ranks (balanced by frames, no communication)
+// and "JOB" in the wspecifier is replaced by rank+1.
+#include <limits>
+
+#include "base/kaldi-common.h"
+#include "cudamatrix/cu-device.h"
+#include "nnet/nnet-nnet.h"
+#include "nnetbin/dist-utils.h"
+#include "util/common-utils.h"
+#include "util/timer.h"
+
+namespace {
+void CheckFinite(const kaldi::Matrix<kaldi::BaseFloat> &m, const char *what, const std::string &key) {
+  using kaldi::BaseFloat;
+  for (kaldi::int32 r = 0; r < m.NumRows(); ++r) {
+    const BaseFloat *row = m.RowData(r);
+    for (kaldi::int32 c = 0; c < m.NumCols(); ++c) {
+      if (row[c] != row[c]) KALDI_ERR << "NaN in " << what << " of : " << key;
+      if (row[c] == std::numeric_limits<BaseFloat>::infinity()) KALDI_ERR << "inf in " << what << " of : " << key;
+    }
+  }
+}
+}  // namespace
+
+int main(int argc, char *argv[]) {
+  using namespace kaldi;
+  try {
+    const char *usage =
+        "Perform forward pass through Neural Network.\n"
+        "Usage:  nnet-forward [options] <model-in> <feature-rspecifier> <feature-wspecifier>\n"
+        "e.g.: \n"
+        " nnet-forward nnet ark:features.ark ark:mlpoutput.ark\n";
+
+    ParseOptions po(usage);
+    std::string feature_transform;
+    po.Register("feature-transform", &feature_transform, "Feature transform Neural Network");
+    std::string class_frame_counts;
+    po.Register("class-frame-counts", &class_frame_counts, "Counts of frames for posterior division by class-priors");
+    BaseFloat prior_scale = 1.0;
+    po.Register("prior-scale", &prior_scale, "scaling factor of prior log-probabilites given by --class-frame-counts");
+    bool apply_log = false, silent = false, no_softmax = false;
+    po.Register("apply-log", &apply_log, "Transform MLP output to logscale");
+    po.Register("no-softmax", &no_softmax,
+                "No softmax on MLP output. The MLP outputs directly log-likelihoods, log-priors will be subtracted");
+    po.Register("silent", &silent, "Don't print any messages");
+    bool fused = true;
+    po.Register("fused", &fused, "Run the linearity+activation pairs as fused GPU kernels");
+    DistOptions dist;
+    dist.Register(&po);
+
+    po.Read(argc, argv);
+    if (po.NumArgs() != 3) {
+      po.PrintUsage();
+      exit(1);
+    }
+    std::string model_filename = po.GetArg(1), feature_rspecifier = po.GetArg(2), feature_wspecifier = po.GetArg(3);
+
+    dist.Resolve();
+    if (silent) CuDevice::Instantiate().Verbose(false);
+    DistInit(dist);
+    if (dist.num_ranks > 1) feature_wspecifier = SubstituteJob(feature_wspecifier, dist.rank);
+
+    Nnet nnet_transf;
+    if (feature_transform != "") nnet_transf.Read(feature_transform);
+    Nnet nnet;
+    nnet.Read(model_filename);
+    nnet.SetFusion(fused);
+    nnet_transf.SetFusion(fused);
+
+    kaldi::int64 tot_t = 0;
+    SequentialBaseFloatMatrixReader feature_reader(feature_rspecifier);
+    BaseFloatMatrixWriter feature_writer(feature_wspecifier);
+
+    CuMatrix<BaseFloat> feats, feats_transf, nnet_out;
+    Matrix<BaseFloat> nnet_out_host;
+
+    // class priors from frame counts: log-domain offset or linear-domain scale
+    Vector<BaseFloat> tmp_priors;
+    CuVector<BaseFloat> priors;
+    if (class_frame_counts != "") {
+      Input in;
+      in.OpenTextMode(class_frame_counts);
+      tmp_priors.Read(in.Stream(), false);
+      in.Close();
+      tmp_priors.Scale(1.0 / tmp_priors.Sum());
+      if (apply_log || no_softmax) {
+        tmp_priors.ApplyLog();
+        tmp_priors.Scale(-prior_scale);
+      } else {
+        tmp_priors.ApplyPow(-prior_scale);
+      }
+      priors.CopyFromVec(tmp_priors);
+    }
+
+    Timer tim;
+    if (!silent) KALDI_LOG << "MLP FEEDFORWARD STARTED";
+
+    ShardAssigner shard(dist.num_ranks);
+    int32 num_done = 0;
+    for (; !feature_reader.Done(); feature_reader.Next()) {
+      const Matrix<BaseFloat> &mat = feature_reader.Value();
+      if (shard.Assign(mat.NumRows()) != dist.rank) continue;
+      CheckFinite(mat, "features", feature_reader.Key());
+      feats.CopyFromMat(mat);
+      nnet_transf.Feedforward(feats, &feats_transf);
+      nnet.Feedforward(feats_transf, &nnet_out);
+      if (apply_log) nnet_out.ApplyLog();
+      if (class_frame_counts != "") {
+        if (apply_log || no_softmax) nnet_out.AddVecToRows(1.0, priors, 1.0);
+        else nnet_out.MulColsVec(priors);
+      }
+      nnet_out.CopyToMat(&nnet_out_host);
+      CheckFinite(nnet_out_host, "NNet output", feature_reader.Key());
+      feature_writer.Write(feature_reader.Key(), nnet_out_host);
+      if (num_done % 1000 == 0 && !silent) KALDI_LOG << num_done << ", " << std::flush;
+      num_done++;
+      tot_t += mat.NumRows();
+    }
+
+    if (!silent) KALDI_LOG << "MLP FEEDFORWARD FINISHED " << tim.Elapsed() << "s, fps" << tot_t / tim.Elapsed();
+    if (!silent) KALDI_LOG << "Done " << num_done << " files";
+    if (!silent) CuDevice::Instantiate().PrintProfile();
+    DistFinalize(dist);
+    return ((num_done > 0) ? 0 : 1);
+  } catch (const std::exception &e) {
+    std::cerr << e.what();
+    return -1;
+  }
+}

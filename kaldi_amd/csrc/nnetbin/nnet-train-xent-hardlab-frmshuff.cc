@@ -1,0 +1,190 @@
+// nnet-train-xent-hardlab-frmshuff: one epoch of frame-shuffled minibatch SGD with the
+// cross-entropy objective and hard (alignment) labels.  Command line, defaults, log lines and
+// exit codes of the reference tool (nnetbin/nnet-train-xent-hardlab-frmshuff.cc:27-209); the
+// multi-GPU options (--num-ranks ...) are additions: synchronous data-parallel training, each
+// rank on its shard of the utterances, gradients summed with an RCCL all-reduce per layer.
+#include "base/kaldi-common.h"
+#include "cudamatrix/cu-device.h"
+#include "nnet/nnet-cache.h"
+#include "nnet/nnet-loss.h"
+#include "nnet/nnet-nnet.h"
+#include "nnetbin/dist-utils.h"
+#include "util/common-utils.h"
+#include "util/timer.h"
+
+int main(int argc, char *argv[]) {
+  using namespace kaldi;
+  try {
+    const char *usage =
+        "Perform iteration of Neural Network training by stochastic gradient descent.\n"
+        "Usage:  nnet-train-xent-hardlab-frmshuff [options] <feature-rspecifier> <alignments-rspecifier> <model-in> "
+        "[<model-out>]\n"
+        "e.g.: \n"
+        " nnet-train-xent-hardlab-perutt scp:train.scp ark:train.ali nnet.init nnet.iter1\n";
+
+    ParseOptions po(usage);
+    bool binary = false, crossvalidate = false, randomize = true;
+    po.Register("binary", &binary, "Write output in binary mode");
+    po.Register("cross-validate", &crossvalidate, "Perform cross-validation (don't backpropagate)");
+    po.Register("randomize", &randomize, "Perform the frame-level shuffling within the Cache::");
+
+    BaseFloat learn_rate = 0.008, momentum = 0.0, l2_penalty = 0.0, l2_upper_bound = 0.0, l1_penalty = 0.0;
+    po.Register("learn-rate", &learn_rate, "Learning rate");
+    po.Register("momentum", &momentum, "Momentum");
+    po.Register("l2-penalty", &l2_penalty, "L2 penalty (weight decay)");
+    po.Register("l2-upper-bound", &l2_upper_bound, "L2 upper bound (>=1.0)");
+    po.Register("l1-penalty", &l1_penalty, "L1 penalty (promote sparsity)");
+
+    bool average_grad = false;
+    po.Register("average-grad", &average_grad, "Whether to average the gradient in the bunch");
+    std::string learn_factors = "";
+    po.Register("learn-factors", &learn_factors,
+                "Learning factor for each updatable layer, separated by ',' and work together with learn rate");
+    std::string feature_transform;
+    po.Register("feature-transform", &feature_transform, "Feature transform Neural Network");
+
+    int32 bunchsize = 512, cachesize = 32768;
+    po.Register("bunchsize", &bunchsize, "Size of weight update block");
+    po.Register("cachesize", &cachesize, "Size of cache for frame level shuffling");
+
+    bool fused = true, profile = false;
+    po.Register("fused", &fused, "Run the linearity+activation pairs as fused GPU kernels");
+    po.Register("profile", &profile, "Synchronise after every GPU call and print a per-function time profile");
+    DistOptions dist;
+    dist.Register(&po);
+
+    po.Read(argc, argv);
+
+    if (po.NumArgs() != 4 - (crossvalidate ? 1 : 0)) {
+      po.PrintUsage();
+      exit(1);
+    }
+
+    std::string feature_rspecifier = po.GetArg(1), alignments_rspecifier = po.GetArg(2), model_filename = po.GetArg(3);
+    std::string target_model_filename;
+    if (!crossvalidate) target_model_filename = po.GetArg(4);
+
+    dist.Resolve();
+    DistInit(dist);
+    CuDevice::Instantiate().Profile(profile);
+
+    Nnet nnet_transf;
+    if (feature_transform != "") nnet_transf.Read(feature_transform);
+
+    Nnet nnet;
+    nnet.Read(model_filename);
+    nnet.SetLearnRate(learn_rate, learn_factors == "" ? NULL : learn_factors.c_str());
+    nnet.SetMomentum(momentum);
+    nnet.SetL2Penalty(l2_penalty);
+    nnet.SetL2UpperBound(l2_upper_bound);
+    nnet.SetL1Penalty(l1_penalty);
+    nnet.SetAverageGrad(average_grad);
+    nnet.SetFusion(fused);
+    nnet_transf.SetFusion(fused);
+    if (dist.num_ranks > 1 && !crossvalidate) nnet.SetDataParallel(dist.num_ranks);
+
+    kaldi::int64 tot_t = 0;
+
+    SequentialBaseFloatMatrixReader feature_reader(feature_rspecifier);
+    RandomAccessInt32VectorReader alignments_reader(alignments_rspecifier);
+
+    Cache cache;
+    cachesize = (cachesize / bunchsize) * bunchsize;  // a whole number of bunches
+    cache.Init(cachesize, bunchsize);
+
+    Xent xent;
+
+    CuMatrix<BaseFloat> feats, feats_transf, nnet_in, nnet_out, glob_err;
+    CuStlVector<int32> targets;
+    ShardAssigner shard(dist.num_ranks);
+
+    Timer tim;
+    double time_next = 0;
+    KALDI_LOG << (crossvalidate ? "CROSSVALIDATE" : "TRAINING") << " STARTED";
+
+    int32 num_done = 0, num_no_alignment = 0, num_other_error = 0, num_cache = 0;
+    while (1) {
+      // fill the cache with this rank's utterances
+      while (!cache.Full() && !feature_reader.Done()) {
+        std::string key = feature_reader.Key();
+        if (!alignments_reader.HasKey(key)) {
+          num_no_alignment++;
+        } else {
+          const Matrix<BaseFloat> &mat = feature_reader.Value();
+          const std::vector<int32> &alignment = alignments_reader.Value(key);
+          if ((int32)alignment.size() != mat.NumRows()) {
+            KALDI_WARN << "Alignment has wrong size " << (alignment.size()) << " vs. " << (mat.NumRows());
+            num_other_error++;
+            // step to the next utterance (the reference retried the same one forever)
+          } else if (shard.Assign(mat.NumRows()) == dist.rank) {
+            for (size_t i = 0; i < alignment.size(); ++i)
+              if (alignment[i] < 0 || alignment[i] >= nnet.OutputDim())
+                KALDI_ERR << "Alignment of " << key << " has label " << alignment[i] << " outside the network's "
+                          << nnet.OutputDim() << " outputs";
+            feats.CopyFromMat(mat);                            // host -> device
+            nnet_transf.Feedforward(feats, &feats_transf);     // optional transform
+            cache.AddData(feats_transf, alignment);
+            num_done++;
+          }
+        }
+        Timer t_features;
+        feature_reader.Next();
+        time_next += t_features.Elapsed();
+      }
+      if (!crossvalidate && randomize) cache.Randomize();
+      std::cerr << "Cache #" << ++num_cache << " " << (cache.Randomized() ? "[RND]" : "[NO-RND]")
+                << " segments: " << num_done << " frames: " << tot_t << "\n";
+
+      if (dist.num_ranks == 1) {
+        while (!cache.Empty()) {
+          cache.GetBunch(&nnet_in, &targets);
+          nnet.Propagate(nnet_in, &nnet_out);
+          xent.EvalVec(nnet_out, targets, &glob_err);
+          if (!crossvalidate) nnet.Backpropagate(glob_err, NULL);
+          tot_t += nnet_in.NumRows();
+        }
+        if (feature_reader.Done()) break;
+      } else {
+        // every rank must take the same number of steps: agree once per cache on the bunch count
+        const int64 bunches = DistAllReduce(dist, cache.NumBunches(), 1 /*min*/);
+        for (int64 b = 0; b < bunches; ++b) {
+          cache.GetBunch(&nnet_in, &targets);
+          nnet.Propagate(nnet_in, &nnet_out);
+          xent.EvalVec(nnet_out, targets, &glob_err);
+          if (!crossvalidate) nnet.Backpropagate(glob_err, NULL);
+          tot_t += nnet_in.NumRows();
+        }
+        // bunches this rank still holds when another rank had fewer are dropped (last cache only:
+        // full caches hold the same number everywhere)
+        while (!cache.Empty()) cache.GetBunch(&nnet_in, &targets);
+        if (DistAllReduce(dist, feature_reader.Done() ? 1 : 0, 2 /*max*/)) break;
+      }
+    }
+
+    CuDevice::Instantiate().Synchronize();
+    if (!crossvalidate && dist.rank == 0) nnet.Write(target_model_filename, binary);
+
+    std::cout << "\n" << std::flush;
+
+    KALDI_LOG << (crossvalidate ? "CROSSVALIDATE" : "TRAINING") << " FINISHED " << tim.Elapsed() << "s, fps"
+              << tot_t / tim.Elapsed() << ", feature wait " << time_next << "s";
+    KALDI_LOG << "Done " << num_done << " files, " << num_no_alignment << " with no alignments, " << num_other_error
+              << " with other errors.";
+    KALDI_LOG << xent.Report();
+    if (dist.num_ranks > 1) {
+      int64 frames, correct;
+      double loss;
+      xent.GetStats(&frames, &correct, &loss);
+      const int64 all_frames = DistAllReduce(dist, frames, 0), all_correct = DistAllReduce(dist, correct, 0);
+      if (dist.rank == 0)
+        KALDI_LOG << "ALL RANKS frames:" << all_frames << " FRAME_ACCURACY_ALL >> " << 100.0 * all_correct / all_frames
+                  << "% << over " << dist.num_ranks << " ranks, fps_all " << all_frames / tim.Elapsed();
+    }
+    CuDevice::Instantiate().PrintProfile();
+    DistFinalize(dist);
+    return 0;
+  } catch (const std::exception &e) {
+    std::cerr << e.what();
+    return -1;
+  }
+}

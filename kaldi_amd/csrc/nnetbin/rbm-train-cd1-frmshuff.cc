@@ -1,0 +1,131 @@
+// rbm-train-cd1-frmshuff: one epoch of contrastive-divergence (CD-1) training of a single RBM
+// on frame-shuffled minibatches.  Command line, defaults and log lines of the reference tool
+// (nnetbin/rbm-train-cd1-frmshuff.cc:29-191).
+#include "base/kaldi-common.h"
+#include "cudamatrix/cu-device.h"
+#include "cudamatrix/cu-rand.h"
+#include "nnet/nnet-cache.h"
+#include "nnet/nnet-loss.h"
+#include "nnet/nnet-nnet.h"
+#include "nnet/nnet-rbm.h"
+#include "util/common-utils.h"
+#include "util/timer.h"
+
+int main(int argc, char *argv[]) {
+  using namespace kaldi;
+  try {
+    const char *usage =
+        "Perform iteration of RBM training by contrastive divergence alg.\n"
+        "Usage:  rbm-train-cd1-frmshuff [options] <model-in> <feature-rspecifier> <model-out>\n"
+        "e.g.: \n"
+        " rbm-train-cd1-frmshuff rbm.init scp:train.scp rbm.iter1\n";
+
+    ParseOptions po(usage);
+    bool binary = false;
+    po.Register("binary", &binary, "Write output in binary mode");
+    BaseFloat learn_rate = 0.008, momentum = 0.0, l2_penalty = 0.0;
+    po.Register("learn-rate", &learn_rate, "Learning rate");
+    po.Register("momentum", &momentum, "Momentum");
+    po.Register("l2-penalty", &l2_penalty, "L2 penalty (weight decay)");
+    std::string feature_transform;
+    po.Register("feature-transform", &feature_transform, "Feature transform Neural Network");
+    int32 bunchsize = 512, cachesize = 32768;
+    po.Register("bunchsize", &bunchsize, "Size of weight update block");
+    po.Register("cachesize", &cachesize, "Size of cache for frame level shuffling");
+    int32 gpu_id = -1;
+    po.Register("gpu-id", &gpu_id, "GPU ordinal (-1: the GPU with most free memory)");
+    bool profile = false;
+    po.Register("profile", &profile, "Synchronise after every GPU call and print a per-function time profile");
+
+    po.Read(argc, argv);
+    if (po.NumArgs() != 3) {
+      po.PrintUsage();
+      exit(1);
+    }
+    std::string model_filename = po.GetArg(1), feature_rspecifier = po.GetArg(2), target_model_filename = po.GetArg(3);
+
+    CuDevice::Instantiate().SelectGpuId(gpu_id);
+    CuDevice::Instantiate().Profile(profile);
+
+    Nnet rbm_transf;
+    if (feature_transform != "") rbm_transf.Read(feature_transform);
+
+    Nnet nnet;
+    nnet.Read(model_filename);
+    KALDI_ASSERT(nnet.LayerCount() == 1);
+    KALDI_ASSERT(nnet.Layer(0)->GetType() == Component::kRbm);
+    RbmBase &rbm = dynamic_cast<RbmBase &>(*nnet.Layer(0));
+    rbm.SetLearnRate(learn_rate);
+    rbm.SetMomentum(momentum);
+    rbm.SetL2Penalty(l2_penalty);
+
+    kaldi::int64 tot_t = 0;
+    SequentialBaseFloatMatrixReader feature_reader(feature_rspecifier);
+
+    Cache cache;
+    cachesize = (cachesize / bunchsize) * bunchsize;
+    cache.Init(cachesize, bunchsize);
+
+    CuRand<BaseFloat> cu_rand;
+    MseProgress mse;
+
+    CuMatrix<BaseFloat> feats, feats_transf, pos_vis, pos_hid, neg_vis, neg_hid, dummy_mse_mat;
+    std::vector<int32> dummy_cache_vec;
+    CuStlVector<int32> dummy_targets;
+
+    Timer tim;
+    double time_next = 0;
+    KALDI_LOG << "RBM TRAINING STARTED";
+
+    int32 num_done = 0, num_cache = 0;
+    while (1) {
+      while (!cache.Full() && !feature_reader.Done()) {
+        const Matrix<BaseFloat> &mat = feature_reader.Value();
+        dummy_cache_vec.resize(mat.NumRows());  // the cache wants labels; RBM training has none
+        feats.CopyFromMat(mat);
+        rbm_transf.Feedforward(feats, &feats_transf);
+        cache.AddData(feats_transf, dummy_cache_vec);
+        num_done++;
+        Timer t_features;
+        feature_reader.Next();
+        time_next += t_features.Elapsed();
+      }
+      cache.Randomize();
+      std::cerr << "Cache #" << ++num_cache << " " << (cache.Randomized() ? "[RND]" : "[NO-RND]")
+                << " segments: " << num_done << " frames: " << tot_t << "\n";
+      while (!cache.Empty()) {
+        cache.GetBunch(&pos_vis, &dummy_targets);
+        // positive phase
+        rbm.Propagate(pos_vis, &pos_hid);
+        // sample the hidden layer to drive the reconstruction
+        if (rbm.HidType() == Rbm::BERNOULLI) {
+          cu_rand.BinarizeProbs(pos_hid, &neg_hid);
+        } else {
+          neg_hid.CopyFromMat(pos_hid);
+          cu_rand.AddGaussNoise(&neg_hid);
+        }
+        // negative phase
+        rbm.Reconstruct(neg_hid, &neg_vis);
+        rbm.Propagate(neg_vis, &neg_hid);
+        rbm.RbmUpdate(pos_vis, pos_hid, neg_vis, neg_hid);
+        mse.Eval(neg_vis, pos_vis, &dummy_mse_mat);
+        tot_t += pos_vis.NumRows();
+      }
+      if (feature_reader.Done()) break;
+    }
+
+    CuDevice::Instantiate().Synchronize();
+    nnet.Write(target_model_filename, binary);
+
+    std::cout << "\n" << std::flush;
+    KALDI_LOG << "RBM TRAINING FINISHED " << tim.Elapsed() << "s, fps" << tot_t / tim.Elapsed() << ", feature wait "
+              << time_next << "s";
+    KALDI_LOG << "Done " << num_done << " files.";
+    KALDI_LOG << mse.Report();
+    CuDevice::Instantiate().PrintProfile();
+    return 0;
+  } catch (const std::exception &e) {
+    std::cerr << e.what();
+    return -1;
+  }
+}

@@ -1,0 +1,322 @@
+// Keyed tables: sequential reader, random-access reader and writer over archives ("ark:") and
+// script files ("scp:"), with the reference's specifier syntax (util/kaldi-table.h:98-203):
+//   rspecifier  [opts,]ark:rxfilename | [opts,]scp:rxfilename      opts: o s cs p (+ n-forms), b t ignored
+//   wspecifier  [opts,]ark:wxfilename | scp:wxfilename | ark,scp:archive,script     opts: b t f nf
+// Archive layout: for each entry  "<key> " + holder payload.  Script layout: "<key> <xfilename>\n".
+#ifndef KALDI_AMD_UTIL_KALDI_TABLE_H_
+#define KALDI_AMD_UTIL_KALDI_TABLE_H_
+#include <memory>
+#include <string>
+#include <unordered_map>
+#include <utility>
+#include <vector>
+
+#include "util/kaldi-holder.h"
+#include "util/kaldi-io.h"
+
+namespace kaldi {
+
+enum WspecifierType { kNoWspecifier, kArchiveWspecifier, kScriptWspecifier, kBothWspecifier };
+struct WspecifierOptions {
+  bool binary, flush;
+  WspecifierOptions() : binary(true), flush(false) {}
+};
+WspecifierType ClassifyWspecifier(const std::string &wspecifier, std::string *archive_wxfilename,
+                                  std::string *script_wxfilename, WspecifierOptions *opts);
+
+enum RspecifierType { kNoRspecifier, kArchiveRspecifier, kScriptRspecifier };
+struct RspecifierOptions {
+  bool once, sorted, called_sorted, permissive;
+  RspecifierOptions() : once(false), sorted(false), called_sorted(false), permissive(false) {}
+};
+RspecifierType ClassifyRspecifier(const std::string &rspecifier, std::string *rxfilename, RspecifierOptions *opts);
+
+/// reads "key xfilename" lines; false on a malformed line
+bool ReadScriptFile(const std::string &rxfilename, bool print_warnings,
+                    std::vector<std::pair<std::string, std::string> > *script_out);
+bool IsToken(const std::string &s);  // non-empty, no whitespace
+
+// ---- sequential reader ---------------------------------------------------------------------
+template <class Holder>
+class SequentialTableReader {
+ public:
+  typedef typename Holder::T T;
+  SequentialTableReader() : type_(kNoRspecifier), done_(true), pos_(0) {}
+  explicit SequentialTableReader(const std::string &rspecifier) : type_(kNoRspecifier), done_(true), pos_(0) {
+    if (!Open(rspecifier)) KALDI_ERR << "Error constructing TableReader: rspecifier is " << rspecifier;
+  }
+  bool Open(const std::string &rspecifier) {
+    rspecifier_ = rspecifier;
+    std::string rx;
+    type_ = ClassifyRspecifier(rspecifier, &rx, &opts_);
+    if (type_ == kArchiveRspecifier) {
+      if (!input_.OpenTextMode(rx)) {
+        KALDI_WARN << "TableReader: failed to open stream " << PrintableRxfilename(rx);
+        return false;
+      }
+    } else if (type_ == kScriptRspecifier) {
+      if (!ReadScriptFile(rx, true, &script_)) return false;
+      pos_ = 0;
+    } else {
+      KALDI_WARN << "Invalid rspecifier " << rspecifier;
+      return false;
+    }
+    done_ = false;
+    Advance();
+    return true;
+  }
+  bool IsOpen() const { return type_ != kNoRspecifier; }
+  bool Done() const { return done_; }
+  std::string Key() const {
+    if (done_) KALDI_ERR << "TableReader: Key() called when Done()";
+    return key_;
+  }
+  const T &Value() {
+    if (done_) KALDI_ERR << "TableReader: Value() called when Done()";
+    return holder_.Value();
+  }
+  void Next() {
+    if (done_) KALDI_ERR << "TableReader: Next() called when Done()";
+    Advance();
+  }
+  bool Close() {
+    input_.Close();
+    type_ = kNoRspecifier;
+    done_ = true;
+    return true;
+  }
+
+ private:
+  void Advance() {
+    if (type_ == kArchiveRspecifier) {
+      std::istream &is = input_.Stream();
+      is.clear();
+      is >> key_;  // skips the whitespace left after the previous entry
+      if (is.eof() || is.fail()) {
+        done_ = true;
+        return;
+      }
+      const int c = is.peek();
+      if (c != ' ' && c != '\t' && c != '\n')
+        KALDI_ERR << "TableReader: invalid archive file format: expected space after key " << key_ << ", got character "
+                  << static_cast<char>(c) << ", reading " << rspecifier_;
+      if (c != '\n') is.get();  // a bare newline belongs to an empty text-mode value
+      if (!holder_.Read(is)) {
+        if (opts_.permissive) {
+          KALDI_WARN << "TableReader: error reading object for key " << key_ << "; ignoring the rest of the archive";
+          done_ = true;
+          return;
+        }
+        KALDI_ERR << "TableReader: failed to read object from archive, key " << key_ << ", reading " << rspecifier_;
+      }
+    } else {
+      while (pos_ < script_.size()) {
+        const std::pair<std::string, std::string> &e = script_[pos_++];
+        key_ = e.first;
+        Input in;
+        if (in.OpenTextMode(e.second) && holder_.Read(in.Stream())) return;
+        if (!opts_.permissive) KALDI_ERR << "TableReader: failed to load object from " << PrintableRxfilename(e.second);
+        KALDI_WARN << "TableReader: skipping key " << key_ << ", cannot read " << PrintableRxfilename(e.second);
+      }
+      done_ = true;
+    }
+  }
+  std::string rspecifier_, key_;
+  RspecifierType type_;
+  RspecifierOptions opts_;
+  Input input_;
+  Holder holder_;
+  bool done_;
+  std::vector<std::pair<std::string, std::string> > script_;
+  size_t pos_;
+};
+
+// ---- random-access reader ------------------------------------------------------------------
+// Archives are consumed lazily: entries are read until the requested key turns up and everything
+// seen on the way is kept.  With the "s" (sorted) option a miss is decided as soon as a larger
+// key has been read; with "o" (once) a value is dropped when the NEXT key is requested, so that
+// the reference returned by Value() stays valid until then.
+template <class Holder>
+class RandomAccessTableReader {
+ public:
+  typedef typename Holder::T T;
+  RandomAccessTableReader() : type_(kNoRspecifier), eof_(true) {}
+  explicit RandomAccessTableReader(const std::string &rspecifier) : type_(kNoRspecifier), eof_(true) {
+    if (!Open(rspecifier)) KALDI_ERR << "Error opening RandomAccessTableReader object (rspecifier is: " << rspecifier << ")";
+  }
+  bool Open(const std::string &rspecifier) {
+    rspecifier_ = rspecifier;
+    std::string rx;
+    type_ = ClassifyRspecifier(rspecifier, &rx, &opts_);
+    if (type_ == kArchiveRspecifier) {
+      if (!input_.OpenTextMode(rx)) return false;
+      eof_ = false;
+    } else if (type_ == kScriptRspecifier) {
+      std::vector<std::pair<std::string, std::string> > script;
+      if (!ReadScriptFile(rx, true, &script)) return false;
+      for (size_t i = 0; i < script.size(); ++i) script_[script[i].first] = script[i].second;
+      eof_ = true;
+    } else {
+      return false;
+    }
+    return true;
+  }
+  bool IsOpen() const { return type_ != kNoRspecifier; }
+  bool HasKey(const std::string &key) { return Find(key) != NULL; }
+  const T &Value(const std::string &key) {
+    const T *t = Find(key);
+    if (!t) KALDI_ERR << "RandomAccessTableReader: Value() called for key " << key << " which is not present, reading " << rspecifier_;
+    return *t;
+  }
+  bool Close() {
+    input_.Close();
+    cache_.clear();
+    type_ = kNoRspecifier;
+    return true;
+  }
+
+ private:
+  const T *Find(const std::string &key) {
+    if (opts_.once && !last_key_.empty() && last_key_ != key) {
+      cache_.erase(last_key_);
+      last_key_.clear();
+    }
+    typename std::unordered_map<std::string, std::unique_ptr<T> >::iterator it = cache_.find(key);
+    if (it != cache_.end()) {
+      last_key_ = key;
+      return it->second.get();
+    }
+    if (type_ == kScriptRspecifier) {
+      std::unordered_map<std::string, std::string>::iterator s = script_.find(key);
+      if (s == script_.end()) return NULL;
+      Input in;
+      Holder h;
+      if (!in.OpenTextMode(s->second) || !h.Read(in.Stream())) {
+        if (opts_.permissive) return NULL;
+        KALDI_ERR << "RandomAccessTableReader: failed to load object from " << PrintableRxfilename(s->second);
+      }
+      cache_[key].reset(new T(h.Value()));
+      last_key_ = key;
+      return cache_[key].get();
+    }
+    if (opts_.sorted && !newest_key_.empty() && key < newest_key_) return NULL;  // would have been seen already
+    while (!eof_) {
+      std::istream &is = input_.Stream();
+      std::string k;
+      is.clear();
+      is >> k;
+      if (is.eof() || is.fail()) {
+        eof_ = true;
+        break;
+      }
+      const int c = is.peek();
+      if (c != ' ' && c != '\t' && c != '\n') KALDI_ERR << "RandomAccessTableReader: invalid archive file format after key " << k;
+      if (c != '\n') is.get();
+      Holder h;
+      if (!h.Read(is)) {
+        if (opts_.permissive) {
+          eof_ = true;
+          break;
+        }
+        KALDI_ERR << "RandomAccessTableReader: failed to read object with key " << k << " from " << rspecifier_;
+      }
+      cache_[k].reset(new T(h.Value()));
+      newest_key_ = k;
+      if (k == key) {
+        last_key_ = key;
+        return cache_[k].get();
+      }
+      if (opts_.sorted && k > key) return NULL;
+    }
+    return NULL;
+  }
+  std::string rspecifier_, last_key_, newest_key_;
+  RspecifierType type_;
+  RspecifierOptions opts_;
+  Input input_;
+  bool eof_;
+  std::unordered_map<std::string, std::unique_ptr<T> > cache_;
+  std::unordered_map<std::string, std::string> script_;
+};
+
+// ---- writer ----------------------------------------------------------------------------------
+template <class Holder>
+class TableWriter {
+ public:
+  typedef typename Holder::T T;
+  TableWriter() : type_(kNoWspecifier) {}
+  explicit TableWriter(const std::string &wspecifier) : type_(kNoWspecifier) {
+    if (!Open(wspecifier)) KALDI_ERR << "TableWriter: failed to write to " << wspecifier;
+  }
+  ~TableWriter() {
+    if (IsOpen() && !Close()) KALDI_WARN << "Error closing TableWriter [in destructor].";
+  }
+  bool Open(const std::string &wspecifier) {
+    wspecifier_ = wspecifier;
+    type_ = ClassifyWspecifier(wspecifier, &archive_name_, &script_name_, &opts_);
+    if (type_ == kNoWspecifier) {
+      KALDI_WARN << "Invalid wspecifier " << wspecifier;
+      return false;
+    }
+    if (type_ == kArchiveWspecifier || type_ == kBothWspecifier) {
+      if (!archive_.Open(archive_name_, opts_.binary, false)) return false;
+      if (type_ == kBothWspecifier && ClassifyWxfilename(archive_name_) != kFileOutput) {
+        KALDI_WARN << "TableWriter: ark,scp output needs a regular archive file, got " << archive_name_;
+        return false;
+      }
+    }
+    if (type_ == kBothWspecifier && !script_.Open(script_name_, false, false)) return false;
+    if (type_ == kScriptWspecifier) {
+      std::vector<std::pair<std::string, std::string> > entries;
+      if (!ReadScriptFile(script_name_, true, &entries)) return false;
+      for (size_t i = 0; i < entries.size(); ++i) script_map_[entries[i].first] = entries[i].second;
+    }
+    return true;
+  }
+  bool IsOpen() const { return type_ != kNoWspecifier; }
+  void Write(const std::string &key, const T &value) {
+    if (!IsToken(key)) KALDI_ERR << "TableWriter: using invalid key " << key;
+    bool ok = true;
+    if (type_ == kScriptWspecifier) {
+      std::unordered_map<std::string, std::string>::iterator it = script_map_.find(key);
+      if (it == script_map_.end()) KALDI_ERR << "TableWriter: key " << key << " not present in script file " << script_name_;
+      Output out;
+      ok = out.Open(it->second, opts_.binary, false) && Holder::Write(out.Stream(), opts_.binary, value) && out.Close();
+    } else {
+      std::ostream &os = archive_.Stream();
+      os << key << ' ';
+      if (type_ == kBothWspecifier) {
+        os.flush();
+        script_.Stream() << key << ' ' << archive_name_ << ':' << static_cast<long long>(os.tellp()) << '\n';
+      }
+      ok = Holder::Write(os, opts_.binary, value);
+      if (opts_.flush) {
+        os.flush();
+        if (type_ == kBothWspecifier) script_.Stream().flush();
+      }
+    }
+    if (!ok) KALDI_ERR << "TableWriter: write failure to " << wspecifier_;
+  }
+  void Flush() {
+    if (archive_.IsOpen()) archive_.Stream().flush();
+    if (script_.IsOpen()) script_.Stream().flush();
+  }
+  bool Close() {
+    bool ok = true;
+    if (archive_.IsOpen()) ok = archive_.Close() && ok;
+    if (script_.IsOpen()) ok = script_.Close() && ok;
+    type_ = kNoWspecifier;
+    return ok;
+  }
+
+ private:
+  std::string wspecifier_, archive_name_, script_name_;
+  WspecifierType type_;
+  WspecifierOptions opts_;
+  Output archive_, script_;
+  std::unordered_map<std::string, std::string> script_map_;
+  KALDI_DISALLOW_COPY_AND_ASSIGN(TableWriter);
+};
+
+}  // namespace kaldi
+#endif

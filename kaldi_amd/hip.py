@@ -25,7 +25,7 @@ class MatrixDim(ctypes.Structure):
 
 _CTYPES = {
     "int": ctypes.c_int, "int32_t": ctypes.c_int32, "float": ctypes.c_float, "size_t": ctypes.c_size_t,
-    "khStream_t": ctypes.c_void_p, "MatrixDim": MatrixDim,
+    "khStream_t": ctypes.c_void_p, "khEvent_t": ctypes.c_void_p, "MatrixDim": MatrixDim,
 }
 
 
@@ -86,6 +86,27 @@ def init(device=-1):
 
 def synchronize():
     call("hipK_device_synchronize")
+
+
+class Timer:
+    """HIP-event timer on the library's default stream (or a given one)."""
+
+    def __init__(self, stream=None):
+        self.stream = stream
+        self.e0, self.e1 = ctypes.c_void_p(), ctypes.c_void_p()
+        call("hipK_event_create", ctypes.byref(self.e0))
+        call("hipK_event_create", ctypes.byref(self.e1))
+
+    def start(self):
+        call("hipK_event_record", self.e0, self.stream)
+
+    def stop(self):
+        """-> elapsed milliseconds (blocks until the stop event has been reached)."""
+        call("hipK_event_record", self.e1, self.stream)
+        call("hipK_event_synchronize", self.e1)
+        ms = ctypes.c_float()
+        call("hipK_event_elapsed_ms", ctypes.byref(ms), self.e0, self.e1)
+        return ms.value
 
 
 class DevMatrix:
