@@ -229,6 +229,12 @@ int rbm1_dims(void *h, int *vis, int *hid) {
   return 0;
   CAPI_CATCH(-1)
 }
+int nnet1_rand_stream(unsigned int seed, int n, int *out) {
+  SRand(seed);
+  for (int i = 0; i < n; ++i) out[i] = Rand();
+  SRand(1);
+  return 0;
+}
 int nnet1_synchronize(void) {
   CAPI_TRY
   CuDevice::Instantiate().Synchronize();

@@ -40,6 +40,8 @@ int rbm1_cd1_bunch(void *h, const float *feats_dev, int ld, int rows, int cols);
 int rbm1_write(void *h, const char *wxfilename, int binary);
 int rbm1_dims(void *h, int *vis, int *hid);
 int nnet1_synchronize(void);
+/* the host random stream (kaldi::Rand after kaldi::SRand(seed)): n draws, for tests */
+int nnet1_rand_stream(unsigned int seed, int n, int *out);
 #ifdef __cplusplus
 }
 #endif

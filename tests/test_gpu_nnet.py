@@ -1,0 +1,296 @@
+"""GPU parity tests of the host C++ layer (Nnet / Xent / Cache / Rbm and the three nnetbin tools)
+against the fixtures produced by the REFERENCE build (tests/golden) and against the CPU oracle.
+
+north_star bar, written out: posteriors within 1e-4 relative, per-minibatch loss and gradients
+within 1e-3 relative, frame-accuracy counts exactly.
+"""
+import ctypes
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import nnet1_oracle as O
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+f32 = np.float32
+
+
+def load(name):
+    return np.load(os.path.join(G, name))
+
+
+@pytest.fixture(scope="module")
+def nn(hip):
+    import kaldi_amd.nnet as n
+    return n
+
+
+def run_tool(nn, name, args, expect_rc=0):
+    exe = os.path.join(nn.BIN_DIR, name)
+    assert os.path.exists(exe), "%s not built" % exe
+    r = subprocess.run([exe] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=110)
+    assert r.returncode == expect_rc, "%s rc=%d\n%s" % (name, r.returncode, r.stderr.decode()[-3000:])
+    return r.stdout, r.stderr.decode()
+
+
+def close_scaled(a, b, rel):
+    b = np.asarray(b)
+    np.testing.assert_allclose(np.asarray(a), b, rtol=rel * 10, atol=rel * max(np.abs(b).max(), 1e-30))
+
+
+@pytest.mark.parametrize("cfg", ["plain", "mom_avg", "l1", "l2ub"])
+@pytest.mark.parametrize("fused", [True, False])
+def test_training_steps_match_reference(hip, nn, tmp_path, cfg, fused):
+    g = load("dnn_small_%s.npz" % cfg)
+    model = tmp_path / "m.nnet"
+    model.write_bytes(g["model_bin"].tobytes())
+    t = nn.Trainer(str(model))
+    t.set_train_opts(float(g["opt_lr"]), float(g["opt_mom"]), float(g["opt_l2"]), float(g["opt_l1"]),
+                     float(g["opt_l2ub"]), bool(g["opt_avg"]), fused)
+    x = hip.DevMatrix.from_numpy(g["x"])
+    tgt = hip.DevMatrix.from_numpy(g["tgt"], pitched=False)
+    N = g["x"].shape[0]
+    for s in range(int(g["opt_nsteps"])):
+        t.train_bunch(x.ptr, x.stride, N, x.cols, tgt.ptr)
+        np.testing.assert_allclose(t.posteriors(N), g["s%d_post" % s], rtol=1e-4, atol=1e-9)       # posteriors 1e-4
+        frames, correct, loss = t.stats()
+        assert frames == int(g["s%d_cumframes" % s])
+        assert abs(100.0 * correct / frames - float(g["s%d_cumacc" % s])) < 1e-3                   # counts exact
+        assert abs(loss - float(g["s%d_cumloss" % s])) <= 1e-3 * abs(loss)                         # loss 1e-3
+        for i in (0, 2, 4):
+            W, b = t.layer_params(i, *g["s%d_W%d" % (s, i)].shape)
+            # weights moved by -lr*gradient: 1e-3 of the step is far below 1e-5 of the weight
+            np.testing.assert_allclose(W, g["s%d_W%d" % (s, i)], rtol=2e-5, atol=2e-6)
+            np.testing.assert_allclose(b, g["s%d_b%d" % (s, i)][0], rtol=2e-5, atol=2e-6)
+    t.close()
+
+
+def test_gradients_match_reference_rm_shape(hip, nn, tmp_path):
+    """One step at the RM size; the gradient is recovered from the weight step taken with a large
+    power-of-two learning rate (so that the step dwarfs the rounding of the weights it is added to)."""
+    g = load("rm_shape_step.npz")
+    rs = np.random.RandomState(int(g["seed"]))
+    dims, N = [int(d) for d in g["dims"]], int(g["N"])
+    layers = []
+    for i in range(len(dims) - 1):
+        W = (0.1 * rs.randn(dims[i + 1], dims[i])).astype(f32)
+        last = i == len(dims) - 2
+        b = np.zeros(dims[i + 1], f32) if last else (-4.1 + 0.2 * rs.rand(dims[i + 1])).astype(f32)
+        layers.append(O.BiasedLinearity(W, b))
+        layers.append(O.Softmax(dims[i + 1]) if last else O.Sigmoid(dims[i + 1]))
+    x = rs.randn(N, dims[0]).astype(f32)
+    tgt = rs.randint(0, dims[-1], N).astype(np.int32)
+    model = tmp_path / "rm.nnet"
+    model.write_bytes(O.write_nnet(layers, True))
+    dx, dt = hip.DevMatrix.from_numpy(x), hip.DevMatrix.from_numpy(tgt, pitched=False)
+    t = nn.Trainer(str(model))
+    t.set_train_opts(0.008)
+    t.train_bunch(dx.ptr, dx.stride, N, dims[0], dt.ptr)
+    post = t.posteriors(N)
+    np.testing.assert_allclose(post[:, :16], g["post_cols"], rtol=1e-4)
+    np.testing.assert_allclose(post[np.arange(N), tgt], g["post_tgt"], rtol=1e-4)
+    assert (post.argmax(1) == g["post_argmax"]).all()
+    frames, correct, loss = t.stats()
+    assert frames == N and abs(100.0 * correct / N - float(g["cumacc"])) < 1e-3
+    assert abs(loss - float(g["cumloss"])) <= 1e-3 * abs(loss)
+    for i in range(0, 2 * (len(dims) - 1), 2):
+        W, b = t.layer_params(i, dims[i // 2 + 1], dims[i // 2])
+        np.testing.assert_allclose(W[:4], g["W%d_rows" % i], rtol=1e-5, atol=1e-7)
+        np.testing.assert_allclose(b, g["b%d" % i], rtol=1e-5, atol=1e-7)
+    t.close()
+    # gradients proper: (W0 - W1) / lr
+    LR = 1024.0
+    t = nn.Trainer(str(model))
+    t.set_train_opts(LR)
+    t.train_bunch(dx.ptr, dx.stride, N, dims[0], dt.ptr)
+    for i in range(0, 2 * (len(dims) - 1), 2):
+        W, b = t.layer_params(i, dims[i // 2 + 1], dims[i // 2])
+        grad = (layers[i].W - W) / f32(LR)
+        close_scaled(grad[:4], g["grad%d_rows" % i], 1e-3)                                          # gradients 1e-3
+        close_scaled((layers[i].b - b) / f32(LR), g["bgrad%d" % i], 1e-3)
+        asum = np.abs(grad.astype(np.float64)).sum()
+        assert abs(asum - float(g["grad%d_abs_sum" % i])) < 2e-3 * float(g["grad%d_abs_sum" % i])
+    t.close()
+
+
+def test_forward_tool_matches_reference(hip, nn, tmp_path):
+    g = load("forward_small.npz")
+    (tmp_path / "m.nnet").write_bytes(g["model"].tobytes())
+    (tmp_path / "m_nosm.nnet").write_bytes(g["model_nosm"].tobytes())
+    (tmp_path / "counts.txt").write_bytes(g["counts_txt"].tobytes())
+    utts = [("utt%d" % i, g["in_utt%d" % i]) for i in range(4)]
+    (tmp_path / "f.ark").write_bytes(O.write_matrix_ark(utts))
+    cnt = "--class-frame-counts=" + str(tmp_path / "counts.txt")
+    variants = {
+        "plain": ("m.nnet", []), "log": ("m.nnet", ["--apply-log=true"]), "counts": ("m.nnet", [cnt]),
+        "counts_log_scale": ("m.nnet", [cnt, "--apply-log=true", "--prior-scale=0.7"]),
+        "nosoftmax_counts": ("m_nosm.nnet", ["--no-softmax=true", cnt]),
+    }
+    for name, (m, opts) in variants.items():
+        out = tmp_path / ("o_%s.ark" % name)
+        _, err = run_tool(nn, "nnet-forward", opts + [str(tmp_path / m), "ark:" + str(tmp_path / "f.ark"), "ark:" + str(out)])
+        assert "MLP FEEDFORWARD FINISHED" in err and "Done 4 files" in err
+        got = dict(O.read_matrix_ark(out.read_bytes()))
+        assert list(got) == [k for k, _ in utts]
+        for k in got:
+            np.testing.assert_allclose(got[k], g["out_%s_%s" % (name, k)], rtol=1e-4, atol=2e-6)
+    # text archive + scp input + unfused path
+    scp = tmp_path / "f.scp"
+    for k, m in utts:
+        (tmp_path / (k + ".mat")).write_bytes(b"\0B" + O.write_matrix(m, True))
+    scp.write_text("".join("%s %s\n" % (k, tmp_path / (k + ".mat")) for k, _ in utts))
+    out = tmp_path / "o_t.ark"
+    run_tool(nn, "nnet-forward", ["--fused=false", "--silent=true", str(tmp_path / "m.nnet"), "scp:" + str(scp),
+                                  "ark,t:" + str(out)])
+    got = dict(O.read_matrix_ark(out.read_bytes()))
+    ref = dict(O.read_matrix_ark(g["out_plain_text_ark"].tobytes()))
+    for k in ref:
+        np.testing.assert_allclose(got[k], ref[k], rtol=1e-4, atol=1e-9)
+    # no utterances -> exit status 1; NaN in the input -> error (-1 = 255)
+    (tmp_path / "empty.ark").write_bytes(b"")
+    run_tool(nn, "nnet-forward", [str(tmp_path / "m.nnet"), "ark:" + str(tmp_path / "empty.ark"), "ark:/dev/null"], 1)
+    bad = utts[0][1].copy()
+    bad[3, 3] = np.nan
+    (tmp_path / "nan.ark").write_bytes(O.write_matrix_ark([("bad", bad)]))
+    _, err = run_tool(nn, "nnet-forward", [str(tmp_path / "m.nnet"), "ark:" + str(tmp_path / "nan.ark"), "ark:/dev/null"], 255)
+    assert "NaN in features of : bad" in err
+
+
+@pytest.mark.parametrize("name,opts", [
+    ("norand", ["--randomize=false"]),
+    ("rand", []),
+    ("norand_mom", ["--randomize=false", "--momentum=0.9", "--learn-rate=0.1", "--average-grad=true"]),
+    ("cv", ["--cross-validate=true"]),
+])
+def test_train_tool_matches_reference(hip, nn, tmp_path, name, opts):
+    """The whole tool: archive readers, cache refills with carried-over rows, the shuffle drawn from
+    rand(), dropped partial bunches, the report line the recipes grep, the written model."""
+    g = load("train_e2e_small.npz")
+    (tmp_path / "m.nnet").write_bytes(g["model"].tobytes())
+    (tmp_path / "f.ark").write_bytes(g["feats_ark"].tobytes())
+    (tmp_path / "a.ark").write_bytes(g["ali_ark_txt"].tobytes())
+    args = ["--bunchsize=16", "--cachesize=64", "--binary=true"] + opts + [
+        "ark:" + str(tmp_path / "f.ark"), "ark:" + str(tmp_path / "a.ark"), str(tmp_path / "m.nnet")]
+    if name != "cv":
+        args.append(str(tmp_path / "out.nnet"))
+    _, err = run_tool(nn, "nnet-train-xent-hardlab-frmshuff", args)
+    assert "\n".join(re.findall(r"Cache #.*", err)) == g[name + "_cache_lines"].tobytes().decode()
+    m = re.search(r"Xent:(\S+) frames:(\d+) err/frm:(\S+)\s*\nFRAME_ACCURACY >> (\S+)% <<", err)
+    assert m, err
+    assert int(m.group(2)) == int(g[name + "_frames"])
+    assert m.group(4) == re.search(r">> (\S+)% <<", g[name + "_report"].tobytes().decode()).group(1)   # exact counts
+    assert abs(float(m.group(1)) - float(g[name + "_xent"])) <= 1e-3 * float(g[name + "_xent"])
+    if name != "cv":
+        got = O.read_nnet((tmp_path / "out.nnet").read_bytes())
+        ref = O.read_nnet(g[name + "_model_out"].tobytes())
+        assert [l.marker for l in got] == [l.marker for l in ref]
+        for a, b in zip(got, ref):
+            if isinstance(a, O.BiasedLinearity):
+                np.testing.assert_allclose(a.W, b.W, rtol=5e-5, atol=5e-6)
+                np.testing.assert_allclose(a.b, b.b, rtol=5e-5, atol=5e-6)
+
+
+def test_train_tool_text_model_and_usage(hip, nn, tmp_path):
+    g = load("train_e2e_small.npz")
+    (tmp_path / "m.nnet").write_bytes(g["model"].tobytes())
+    (tmp_path / "f.ark").write_bytes(g["feats_ark"].tobytes())
+    (tmp_path / "a.ark").write_bytes(g["ali_ark_txt"].tobytes())
+    run_tool(nn, "nnet-train-xent-hardlab-frmshuff", ["--bunchsize=16", "--cachesize=64", "--randomize=false",
+                                                        "ark:" + str(tmp_path / "f.ark"), "ark:" + str(tmp_path / "a.ark"),
+                                                        str(tmp_path / "m.nnet"), str(tmp_path / "out.txt")])
+    got_txt = (tmp_path / "out.txt").read_bytes()
+    ref_txt = g["norand_model_out_txt"].tobytes()
+    assert got_txt[:1] != b"\0"                                     # default --binary=false
+    assert got_txt.count(b"\n") == ref_txt.count(b"\n")             # same text layout, line for line
+    for a, b in zip(O.read_nnet(got_txt), O.read_nnet(ref_txt)):
+        if isinstance(a, O.BiasedLinearity):
+            np.testing.assert_allclose(a.W, b.W, rtol=5e-5, atol=5e-6)
+    # wrong argument count -> usage + exit 1; unknown option -> exit 1
+    _, err = run_tool(nn, "nnet-train-xent-hardlab-frmshuff", ["ark:x"], 1)
+    assert "Usage:  nnet-train-xent-hardlab-frmshuff" in err
+    run_tool(nn, "nnet-train-xent-hardlab-frmshuff", ["--no-such-option=1", "a", "b", "c", "d"], 1)
+
+
+@pytest.mark.parametrize("name", ["bern_bern", "gauss_bern", "bern_gauss"])
+def test_rbm_steps_match_reference(hip, nn, tmp_path, name):
+    """Deterministic sub-steps of CD-1 through the device entry points the Rbm class calls, with
+    the reference's sampled hidden states injected."""
+    h = hip
+    g = load("rbm_small_%s.npz" % name)
+    (rbm,) = O.read_nnet(g["model"].tobytes())
+    V, H, N = rbm.dim_in, rbm.dim_out, g["x"].shape[0]
+    D = h.DevMatrix.from_numpy
+    dW, dvb, dhb = D(rbm.W), D(rbm.vis_bias, False), D(rbm.hid_bias, False)
+    ddW, ddvb, ddhb = D(np.zeros_like(rbm.W)), D(np.zeros(V, f32), False), D(np.zeros(H, f32), False)
+    dpv = D(g["x"])
+    dph, dnh, dnv = h.DevMatrix(N, H), h.DevMatrix(N, H), h.DevMatrix(N, V)
+    hact = h.ACT_SIGMOID if rbm.hid_type == "bern" else h.ACT_NONE
+    vact = h.ACT_SIGMOID if rbm.vis_type == "bern" else h.ACT_NONE
+    for s in range(3):
+        h.call("hipF_affine_forward", None, hact, h.TRANS, N, H, V, dpv.ptr, dpv.stride, dW.ptr, dW.stride, dhb.ptr,
+               dph.ptr, dph.stride)
+        np.testing.assert_allclose(dph.numpy(), g["s%d_pos_hid" % s], rtol=2e-5, atol=2e-6)
+        ds = D(g["s%d_neg_hid_sample" % s])
+        h.call("hipF_affine_forward", None, vact, h.NO_TRANS, N, V, H, ds.ptr, ds.stride, dW.ptr, dW.stride, dvb.ptr,
+               dnv.ptr, dnv.stride)
+        np.testing.assert_allclose(dnv.numpy(), g["s%d_neg_vis" % s], rtol=2e-5, atol=2e-6)
+        h.call("hipF_affine_forward", None, hact, h.TRANS, N, H, V, dnv.ptr, dnv.stride, dW.ptr, dW.stride, dhb.ptr,
+               dnh.ptr, dnh.stride)
+        np.testing.assert_allclose(dnh.numpy(), g["s%d_neg_hid" % s], rtol=2e-5, atol=2e-6)
+        h.call("hipF_rbm_update", None, N, H, V, dpv.ptr, dpv.stride, dph.ptr, dph.stride, dnv.ptr, dnv.stride,
+               dnh.ptr, dnh.stride, f32(g["lr"]), f32(g["mom"]), f32(g["l2"]), dW.ptr, dW.stride, ddW.ptr, ddW.stride,
+               dvb.ptr, ddvb.ptr, dhb.ptr, ddhb.ptr)
+        np.testing.assert_allclose(dW.numpy(), g["s%d_W" % s], rtol=2e-5, atol=2e-6)
+        np.testing.assert_allclose(dvb.numpy()[0], g["s%d_vis_bias" % s][0], rtol=2e-5, atol=2e-6)
+        np.testing.assert_allclose(dhb.numpy()[0], g["s%d_hid_bias" % s][0], rtol=2e-5, atol=2e-6)
+
+
+@pytest.mark.parametrize("vt,ht", [("gauss", "bern"), ("bern", "bern"), ("bern", "gauss")])
+def test_rbm_tool_runs_and_learns(hip, nn, tmp_path, vt, ht):
+    """rbm-train-cd1-frmshuff end to end.  The sampling stream (HybridTaus on the GPU, rand() on the
+    reference's CPU path) cannot be compared draw for draw, so the tool is checked statistically:
+    several epochs reduce the reconstruction error, the model keeps its types and shapes."""
+    rs = np.random.RandomState(5)
+    V, H = 24, 32
+    proto = (rs.rand(4, V) > 0.5).astype(f32)
+    def data(n):
+        x = proto[rs.randint(0, 4, n)]
+        return (x * 0.9 + 0.05 if vt == "bern" else (x - 0.5) * 2 + 0.1 * rs.randn(n, V)).astype(f32)
+    utts = [("u%d" % i, data(n)) for i, n in enumerate([300, 200, 260])]
+    (tmp_path / "f.ark").write_bytes(O.write_matrix_ark(utts))
+    rbm = O.Rbm((0.1 * rs.randn(H, V)).astype(f32), np.zeros(V, f32), np.zeros(H, f32), vt, ht)
+    cur = tmp_path / "rbm0"
+    cur.write_bytes(O.write_nnet([rbm], True))
+    def recon_err(path):
+        (r,) = O.read_nnet(path.read_bytes())
+        x = np.concatenate([m for _, m in utts])
+        return float(((r.reconstruct(r.propagate(x)) - x) ** 2).mean())
+    e0 = recon_err(cur)
+    for ep in range(4):
+        nxt = tmp_path / ("rbm%d" % (ep + 1))
+        _, err = run_tool(nn, "rbm-train-cd1-frmshuff", ["--learn-rate=0.05", "--momentum=0.5", "--l2-penalty=0.0002",
+                                                         "--bunchsize=64", "--cachesize=512", "--binary=true",
+                                                         str(cur), "ark:" + str(tmp_path / "f.ark"), str(nxt)])
+        assert "RBM TRAINING FINISHED" in err and "Done 3 files." in err
+        cur = nxt
+    (r,) = O.read_nnet(cur.read_bytes())
+    assert (r.vis_type, r.hid_type, r.W.shape) == (vt, ht, (H, V))
+    assert recon_err(cur) < 0.7 * e0
+
+
+def test_cache_and_host_io_errors(hip, nn, tmp_path):
+    # model with mismatched layer dims is rejected like the reference does
+    rs = np.random.RandomState(1)
+    bad = [O.BiasedLinearity(rs.randn(5, 4), np.zeros(5)), O.Sigmoid(5), O.BiasedLinearity(rs.randn(3, 6), np.zeros(3))]
+    (tmp_path / "bad.nnet").write_bytes(O.write_nnet(bad, True))
+    with pytest.raises(nn.NnetError, match="Dimensionality mismatch"):
+        nn.Trainer(str(tmp_path / "bad.nnet"))
+    (tmp_path / "junk.nnet").write_bytes(b"<nosuchlayer> 3 3 \n")
+    with pytest.raises(nn.NnetError, match="Unknown marker"):
+        nn.Trainer(str(tmp_path / "junk.nnet"))
+    with pytest.raises(nn.NnetError):
+        nn.Trainer(str(tmp_path / "does_not_exist"))
