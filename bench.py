@@ -1,0 +1,241 @@
+#!/usr/bin/env python3
+"""Benchmark of the nnet1 training hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W          (N=1; N>1 is launched by torch.distributed.run)
+
+A step is one minibatch of nnet-train-xent-hardlab-frmshuff's inner loop -- the bunch copy out of
+the frame cache, Nnet::Propagate, Xent::EvalVec, Nnet::Backpropagate with the SGD update --
+driven through the same C++ objects the tool uses (libkaldi_nnet.so).  Workload: the
+Switchboard-scale 1320 -> 7x2048 sigmoid -> 9000 softmax DNN, bunch 256, fp32, synthetic
+features N(0,1), uniform labels, weights 0.1*N(0,1), hidden biases U(-4.1,-3.9), lr 0.008,
+momentum 0.  With N > 1 every rank trains on its own bunches and the per-layer gradients are summed
+with an RCCL all-reduce (synchronous data parallel, weak scaling: 256 frames per GPU per step).
+
+Prints ONE JSON line on rank 0: frames/s over all GPUs, the roofline of the dominant kernel (the
+fp32 MFMA GEMM: algorithmic FLOPs over the time of its launches, HIP events on their stream) and
+the reference CPU implementation timed on this box's host cores on a bounded sample.
+"""
+import argparse
+import ctypes
+import json
+import os
+import re
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+F32_MFMA_PEAK_TFLOPS = 157.3   # MI355X dense fp32 matrix peak (256 CU x 4 SIMD x 64 FLOP/clk x 2.4 GHz)
+WORKLOADS = {
+    "swbd": dict(dims=[1320] + [2048] * 7 + [9000], name="swbd-1320-7x2048-9000-xent-train"),
+    "rm": dict(dims=[440, 1024, 1024, 1024, 1024, 1483], name="rm-440-4x1024-1483-xent-train"),
+}
+BUNCH = 256
+
+
+def flops_per_frame(dims):
+    """2*MAC over the GEMMs of one training frame: forward 2P, weight gradient 2P, input gradient
+    2(P - P1) (the first layer's input gradient is never computed)."""
+    p = [dims[i] * dims[i + 1] for i in range(len(dims) - 1)]
+    return 6 * sum(p) - 2 * p[0]
+
+
+def write_model(path, dims, seed):
+    """random-init sigmoid DNN in the nnet1 binary format"""
+    rs = np.random.RandomState(seed)
+    with open(path, "wb") as f:
+        f.write(b"\0B")
+        for i in range(len(dims) - 1):
+            o, n = dims[i + 1], dims[i]
+            last = i == len(dims) - 2
+            W = (0.1 * rs.standard_normal((o, n))).astype("<f4")
+            b = np.zeros(o, "<f4") if last else (-4.1 + 0.2 * rs.random_sample(o)).astype("<f4")
+            hdr = lambda tok, a, c: tok + b" " + b"\x04" + np.int32(a).tobytes() + b"\x04" + np.int32(c).tobytes()
+            f.write(hdr(b"<biasedlinearity>", o, n))
+            f.write(hdr(b"FM", o, n))
+            f.write(W.tobytes())
+            f.write(b"FV " + b"\x04" + np.int32(o).tobytes())
+            f.write(b.tobytes())
+            f.write(hdr(b"<softmax>" if last else b"<sigmoid>", o, o))
+
+
+def cpu_baseline(dims, model_path, tmp, frames=4096):
+    """The reference's own nnet-train-xent-hardlab-frmshuff (built from /root/reference into
+    oracle/_ref with HAVE_CUDA off, BLAS = OpenBLAS) on `frames` synthetic frames of the same
+    workload; throughput from its compute loop wall time.  Falls back to the numpy oracle."""
+    exe = os.path.join(ROOT, "oracle", "_ref", "bin", "nnet-train-xent-hardlab-frmshuff")
+    cores = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, os.cpu_count() or 1)
+    rs = np.random.RandomState(11)
+    nutt = max(1, frames // 512)
+    from oracle import nnet1_oracle as O
+    utts = [("utt%03d" % i, rs.standard_normal((512, dims[0])).astype(np.float32)) for i in range(nutt)]
+    alis = [(k, rs.randint(0, dims[-1], 512)) for k, _ in utts]
+    sample = "%d frames (%d utterances x 512), bunch %d, same model" % (nutt * 512, nutt, BUNCH)
+    if os.path.exists(exe):
+        fa, aa = os.path.join(tmp, "cpu_feats.ark"), os.path.join(tmp, "cpu_ali.ark")
+        open(fa, "wb").write(O.write_matrix_ark(utts))
+        open(aa, "wb").write(O.write_int32_vector_ark(alis))
+        env = dict(os.environ, OPENBLAS_NUM_THREADS=str(cores), OMP_NUM_THREADS=str(cores))
+        t0 = time.time()
+        r = subprocess.run([exe, "--bunchsize=%d" % BUNCH, "--cachesize=%d" % (nutt * 512), "--randomize=false",
+                            "--binary=true", "ark:" + fa, "ark:" + aa, model_path, os.path.join(tmp, "cpu_out.nnet")],
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+        wall = time.time() - t0
+        err = r.stderr.decode()
+        m = re.search(r"TRAINING FINISHED (\S+)s, fps(\S+),", err)
+        if r.returncode == 0 and m:
+            # the tool's own fps covers its whole main loop (archive reading included), as the recipes log it
+            return dict(value=float(m.group(2)), unit="frames/s", cores=cores, kind="reference",
+                        sample=sample + "; tool's own fps line, wall %.1fs incl. model load/write" % wall,
+                        blas="OpenBLAS (scipy), %d threads" % cores)
+    # numpy restatement of the same step
+    layers = O.read_nnet(open(model_path, "rb").read())
+    net = O.Nnet(layers)
+    net.set_train_opts(0.008)
+    x, t = utts[0][1][:BUNCH], np.asarray(alis[0][1][:BUNCH])
+    t0 = time.time()
+    n = 0
+    while time.time() - t0 < 10.0:
+        post = net.propagate(x)
+        diff, _, _, _ = O.Xent().eval_vec(post, t)
+        net.backpropagate(diff)
+        n += BUNCH
+    return dict(value=n / (time.time() - t0), unit="frames/s", cores=cores, kind="port",
+                sample="numpy oracle, %d frames" % n)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="swbd", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" %
+                     (args.gpus, args.gpus))
+        args.gpus = world
+
+    import torch  # plumbing only: rendezvous, barrier, max-over-ranks
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    from kaldi_amd import hip as h
+    from kaldi_amd import nnet as nn
+    h.init(local_rank)
+
+    wl = WORKLOADS[args.workload]
+    dims = wl["dims"]
+    tmp = tempfile.mkdtemp(prefix="kaldi_amd_bench_")
+    model_path = os.path.join(tmp, "model.nnet")
+    write_model(model_path, dims, seed=1)   # same weights on every rank, like a shared model-in file
+
+    if world > 1:
+        # RCCL communicator of the device library: rank 0 creates the id, torch broadcasts the bytes
+        uid = (ctypes.c_ubyte * h.COMM_ID_BYTES)()
+        if rank == 0:
+            h.call("hipK_comm_get_unique_id", uid)
+        t_uid = torch.tensor(list(uid), dtype=torch.uint8, device="cuda")
+        dist.broadcast(t_uid, 0)
+        uid = (ctypes.c_ubyte * h.COMM_ID_BYTES)(*t_uid.cpu().tolist())
+        h.call("hipK_comm_init", uid, rank, world)
+
+    trainer = nn.Trainer(model_path)
+    trainer.set_train_opts(0.008)
+    if world > 1:
+        trainer.set_data_parallel(world)
+
+    # a synthetic, already shuffled frame cache resident in HBM (each rank its own frames)
+    cache_rows = 16 * BUNCH
+    rs = np.random.RandomState(100 + rank)
+    cache = h.DevMatrix.from_numpy(rs.standard_normal((cache_rows, dims[0])).astype(np.float32))
+    labels = h.DevMatrix.from_numpy(rs.randint(0, dims[-1], cache_rows).astype(np.int32), pitched=False)
+    nb = cache_rows // BUNCH
+
+    def step(i):
+        b = i % nb
+        trainer.train_bunch(ctypes.c_void_p(cache.ptr.value + b * BUNCH * cache.stride * 4), cache.stride, BUNCH,
+                            dims[0], ctypes.c_void_p(labels.ptr.value + b * BUNCH * 4))
+
+    def fence():
+        nn.synchronize()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    for i in range(args.warmup):
+        step(i)
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    nn.synchronize()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        dist.barrier()
+        t_el = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t_el, op=dist.ReduceOp.MAX)
+        elapsed = float(t_el.item())
+
+    frames, correct, loss = trainer.stats()
+    value = world * BUNCH * args.steps / elapsed
+
+    # roofline of the dominant kernel: GEMM launches timed one by one with HIP events on their stream
+    roof_steps = min(args.steps, 50)
+    h.call("hipK_gemm_timing", 1)
+    for i in range(roof_steps):
+        step(i)
+    ms, launches, fl = ctypes.c_double(), ctypes.c_longlong(), ctypes.c_double()
+    h.call("hipK_gemm_timing_read", ctypes.byref(ms), ctypes.byref(launches), ctypes.byref(fl))
+    h.call("hipK_gemm_timing", 0)
+    fence()
+
+    if rank == 0:
+        fpf = flops_per_frame(dims)
+        achieved = fl.value / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0
+        out = {
+            "metric": "DNN train frames/sec (fwd+bwd+update), %s" % args.workload,
+            "value": round(value, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": wl["name"], "bunch_per_gpu": BUNCH, "global_bunch": BUNCH * world,
+                       "parallelism": "dp%d" % world if world > 1 else "single", "flops_per_frame": fpf,
+                       "pct_fp32_mfma_peak_end_to_end": round(100.0 * value * fpf / world / (F32_MFMA_PEAK_TFLOPS * 1e12), 2)},
+            "roofline": {"bound": "mfma", "kernel": "gemm_kernel (fp32 v_mfma_f32_32x32x2_f32, all layouts)",
+                         "achieved": round(achieved, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                         "launches_per_step": launches.value / roof_steps,
+                         "gemm_ms_per_step": round(ms.value / roof_steps, 4),
+                         "flops_per_step": fl.value / roof_steps},
+            "check": {"frames": frames, "mean_xent": round(loss / max(frames, 1), 4)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(dims, model_path, tmp)
+        print(json.dumps(out), flush=True)
+
+    trainer.close()
+    if world > 1:
+        h.call("hipK_comm_destroy")
+        dist.barrier()
+        dist.destroy_process_group()
+    for f in os.listdir(tmp):
+        os.remove(os.path.join(tmp, f))
+    os.rmdir(tmp)
+
+
+if __name__ == "__main__":
+    main()

@@ -216,6 +216,13 @@ int hipF_add_gauss_noise(khStream_t s, float *mat, float gscale, uint32_t *z1, u
 int hipF_gemm(khStream_t s, int transA, int transB, int32_t M, int32_t N, int32_t K, float alpha,
               const float *A, int32_t lda, const float *B, int32_t ldb, float beta, float *C, int32_t ldc);
 
+/* Measurement aid: with timing enabled every GEMM main-kernel launch (hipF_gemm and the fused
+ * affine / rbm entry points) is bracketed by two HIP events on its stream.  hipK_gemm_timing_read
+ * blocks until they have completed, returns the summed kernel time, the number of launches and
+ * their algorithmic FLOPs (2*M*N*K each), and clears the record.  Off by default. */
+int hipK_gemm_timing(int enable);
+int hipK_gemm_timing_read(double *total_ms, long long *launches, double *flops);
+
 /* Bytes of scratch hipF_gemm_ex / the fused entry points want for a given problem; the library
  * keeps one such workspace per process and grows it on demand (blocking), so callers only need
  * this to pre-size it before capturing a graph. */

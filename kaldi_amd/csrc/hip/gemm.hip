@@ -20,6 +20,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <vector>
+
 #include "common.h"
 
 namespace kh {
@@ -438,6 +440,48 @@ void launch_reduce(hipStream_t st, const GemmParams &p, const float *slabs, int 
     hipLaunchKernelGGL((slab_reduce_kernel<EPI, 1>), dim3(gx, gy), dim3(256), 0, st, p, slabs, ld_slab);
 }
 
+// ---- optional per-launch timing -------------------------------------------------------------------
+struct GemmTiming {
+  bool enabled = false;
+  std::vector<hipEvent_t> pool;                          // recycled events
+  std::vector<std::pair<hipEvent_t, hipEvent_t> > spans;  // one per launch since the last read
+  double flops = 0.0;
+};
+GemmTiming &timing() {
+  static GemmTiming t;
+  return t;
+}
+hipEvent_t timing_event() {
+  GemmTiming &t = timing();
+  hipEvent_t e;
+  if (!t.pool.empty()) {
+    e = t.pool.back();
+    t.pool.pop_back();
+  } else if (hipEventCreate(&e) != hipSuccess) {
+    return nullptr;
+  }
+  return e;
+}
+struct TimedLaunch {
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  hipStream_t st;
+  TimedLaunch(hipStream_t s, double fl) : st(s) {
+    if (!timing().enabled) return;
+    e0 = timing_event();
+    e1 = timing_event();
+    if (e0 && e1) {
+      (void)hipEventRecord(e0, st);
+      timing().flops += fl;
+    }
+  }
+  ~TimedLaunch() {
+    if (e0 && e1) {
+      (void)hipEventRecord(e1, st);
+      timing().spans.push_back(std::make_pair(e0, e1));
+    }
+  }
+};
+
 // Runs op(A)*op(B) and the epilogue EPI.  `softmax` selects the row-softmax finish (always via
 // slabs, since a row spans many tiles).
 template <int EPI>
@@ -450,7 +494,9 @@ int run_gemm(khStream_t s, bool a_kmajor, bool b_kmajor, GemmParams p, bool allo
   p.tiles_n = (p.N + bn - 1) / bn;
   p.splitk = plan.splitk;
   p.k_per_split = plan.k_per_split;
+  const double flops = 2.0 * p.M * p.N * p.K;
   if (p.splitk == 1 && !softmax) {
+    TimedLaunch tl(st, flops);
     launch_layout<EPI>(st, p, plan.cfg, vec, a_kmajor, b_kmajor);
     return kh::launch_status();
   }
@@ -464,7 +510,10 @@ int run_gemm(khStream_t s, bool a_kmajor, bool b_kmajor, GemmParams p, bool allo
   ps.C = (float *)ws;
   ps.ldc = ld_slab;
   ps.slab_stride = slab_stride;
-  launch_layout<EPI_SLAB>(st, ps, plan.cfg, vec, a_kmajor, b_kmajor);
+  {
+    TimedLaunch tl(st, flops);
+    launch_layout<EPI_SLAB>(st, ps, plan.cfg, vec, a_kmajor, b_kmajor);
+  }
   rc = kh::launch_status();
   if (rc != KH_OK) return rc;
   p.slab_stride = slab_stride;
@@ -608,6 +657,30 @@ KH_EXPORT int hipF_affine_apply(khStream_t s, int32_t O, int32_t I, const float 
   hipLaunchKernelGGL(bias_apply_kernel, dim3((O + 255) / 256), dim3(256), 0, st, O, bgrad, gscale, momentum, lr, bias,
                      bcorr);
   return kh::launch_status();
+}
+
+KH_EXPORT int hipK_gemm_timing(int enable) {
+  timing().enabled = enable != 0;
+  return KH_OK;
+}
+
+KH_EXPORT int hipK_gemm_timing_read(double *total_ms, long long *launches, double *flops) {
+  GemmTiming &t = timing();
+  double ms = 0.0;
+  for (size_t i = 0; i < t.spans.size(); ++i) {
+    KH_HIP(hipEventSynchronize(t.spans[i].second));
+    float one = 0.f;
+    KH_HIP(hipEventElapsedTime(&one, t.spans[i].first, t.spans[i].second));
+    ms += one;
+    t.pool.push_back(t.spans[i].first);
+    t.pool.push_back(t.spans[i].second);
+  }
+  if (total_ms) *total_ms = ms;
+  if (launches) *launches = (long long)t.spans.size();
+  if (flops) *flops = t.flops;
+  t.spans.clear();
+  t.flops = 0.0;
+  return KH_OK;
 }
 
 KH_EXPORT int hipF_gemm(khStream_t s, int transA, int transB, int32_t M, int32_t N, int32_t K, float alpha,

@@ -33,6 +33,8 @@ def _arg_type(decl):
     decl = decl.strip()
     if "*" in decl or "[" in decl:
         return ctypes.c_void_p
+    if decl.startswith("double "):
+        return ctypes.c_double
     toks = [t for t in re.split(r"\s+", decl) if t not in ("const", "unsigned")]
     base = toks[0]
     if base == "long":
