@@ -223,6 +223,11 @@ int hipF_gemm(khStream_t s, int transA, int transB, int32_t M, int32_t N, int32_
 int hipK_gemm_timing(int enable);
 int hipK_gemm_timing_read(double *total_ms, long long *launches, double *flops);
 
+/* Tuning aid: pin the tile (bm x bn) and the split-K factor of every following GEMM instead of
+ * letting the library choose; zeros restore the automatic choice.  Also settable at start-up with
+ * the environment variable KALDI_HIP_GEMM_FORCE="bm,bn,splitk". */
+int hipK_gemm_force_plan(int bm, int bn, int splitk);
+
 /* Bytes of scratch hipF_gemm_ex / the fused entry points want for a given problem; the library
  * keeps one such workspace per process and grows it on demand (blocking), so callers only need
  * this to pre-size it before capturing a graph. */

@@ -134,88 +134,98 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
 
   float4 ra[A_UNITS], rb[B_UNITS];
 
-  auto load_a = [&](int k0) {
+  // Loads of one K-tile into registers, two forms.
+  // fast: VEC layout and every k of the tile inside [kbeg,kend).  Unconditional 16-byte loads from
+  //   per-thread base pointers -- rows / columns past the matrix edge are redirected to the last
+  //   valid one, their products only reach output elements that are never stored -- so all loads
+  //   of a tile are in flight together and no wait sits between them.
+  // slow: guarded element-wise loads with zero fill (the K-tail tile, unaligned operands).
+  const float *pa[A_UNITS], *pb[B_UNITS];
+  size_t a_step, b_step;  // pointer advance per K-tile
+  {
+    const int a_xlast = ((p.M - 1) >> 2) << 2, b_xlast = ((p.N - 1) >> 2) << 2;
 #pragma unroll
     for (int u = 0; u < A_UNITS; ++u) {
       const int unit = tid + u * NT;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (A_KMAJOR) {
+        const int row = unit / (BK / 4), kq = unit % (BK / 4);
+        pa[u] = p.A + (size_t)min(m0 + row, p.M - 1) * p.lda + (kbeg + kq * 4);
+      } else {
+        const int krow = unit / (BM / 4), mq = unit % (BM / 4);
+        pa[u] = p.A + (size_t)(kbeg + krow) * p.lda + min(m0 + mq * 4, a_xlast);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < B_UNITS; ++u) {
+      const int unit = tid + u * NT;
+      if (B_KMAJOR) {
+        const int row = unit / (BK / 4), kq = unit % (BK / 4);
+        pb[u] = p.B + (size_t)min(n0 + row, p.N - 1) * p.ldb + (kbeg + kq * 4);
+      } else {
+        const int krow = unit / (BN / 4), nq = unit % (BN / 4);
+        pb[u] = p.B + (size_t)(kbeg + krow) * p.ldb + min(n0 + nq * 4, b_xlast);
+      }
+    }
+    a_step = A_KMAJOR ? (size_t)BK : (size_t)BK * p.lda;
+    b_step = B_KMAJOR ? (size_t)BK : (size_t)BK * p.ldb;
+  }
+  auto load_fast = [&](int kt) {
+#pragma unroll
+    for (int u = 0; u < A_UNITS; ++u) ra[u] = *reinterpret_cast<const float4 *>(pa[u] + kt * a_step);
+#pragma unroll
+    for (int u = 0; u < B_UNITS; ++u) rb[u] = *reinterpret_cast<const float4 *>(pb[u] + kt * b_step);
+  };
+  auto load_slow = [&](int kt) {
+    const int k0 = kbeg + kt * BK;
+#pragma unroll
+    for (int u = 0; u < A_UNITS; ++u) {
+      const int unit = tid + u * NT;
+      float v[4] = {0.f, 0.f, 0.f, 0.f};
       if (A_KMAJOR) {
         const int row = unit / (BK / 4), kq = unit % (BK / 4);
         const int m = m0 + row, k = k0 + kq * 4;
-        if (m < p.M && k < kend) {
+        if (m < p.M) {
           const float *src = p.A + (size_t)m * p.lda + k;
-          if (VEC) {
-            v = *reinterpret_cast<const float4 *>(src);
-            if (k + 3 >= kend) {
-              if (k + 1 >= kend) v.y = 0.f;
-              if (k + 2 >= kend) v.z = 0.f;
-              v.w = 0.f;
-            }
-          } else {
-            v.x = src[0];
-            if (k + 1 < kend) v.y = src[1];
-            if (k + 2 < kend) v.z = src[2];
-            if (k + 3 < kend) v.w = src[3];
-          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (k + e < kend) v[e] = src[e];
         }
       } else {
         const int krow = unit / (BM / 4), mq = unit % (BM / 4);
         const int k = k0 + krow, m = m0 + mq * 4;
-        if (k < kend && m < p.M) {
+        if (k < kend) {
           const float *src = p.A + (size_t)k * p.lda + m;
-          if (VEC) {
-            v = *reinterpret_cast<const float4 *>(src);
-          } else {
-            v.x = src[0];
-            if (m + 1 < p.M) v.y = src[1];
-            if (m + 2 < p.M) v.z = src[2];
-            if (m + 3 < p.M) v.w = src[3];
-          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (m + e < p.M) v[e] = src[e];
         }
       }
-      ra[u] = v;
+      ra[u] = make_float4(v[0], v[1], v[2], v[3]);
     }
-  };
-  auto load_b = [&](int k0) {
 #pragma unroll
     for (int u = 0; u < B_UNITS; ++u) {
       const int unit = tid + u * NT;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      float v[4] = {0.f, 0.f, 0.f, 0.f};
       if (B_KMAJOR) {
         const int row = unit / (BK / 4), kq = unit % (BK / 4);
         const int n = n0 + row, k = k0 + kq * 4;
-        if (n < p.N && k < kend) {
+        if (n < p.N) {
           const float *src = p.B + (size_t)n * p.ldb + k;
-          if (VEC) {
-            v = *reinterpret_cast<const float4 *>(src);
-            if (k + 3 >= kend) {
-              if (k + 1 >= kend) v.y = 0.f;
-              if (k + 2 >= kend) v.z = 0.f;
-              v.w = 0.f;
-            }
-          } else {
-            v.x = src[0];
-            if (k + 1 < kend) v.y = src[1];
-            if (k + 2 < kend) v.z = src[2];
-            if (k + 3 < kend) v.w = src[3];
-          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (k + e < kend) v[e] = src[e];
         }
       } else {
         const int krow = unit / (BN / 4), nq = unit % (BN / 4);
         const int k = k0 + krow, n = n0 + nq * 4;
-        if (k < kend && n < p.N) {
+        if (k < kend) {
           const float *src = p.B + (size_t)k * p.ldb + n;
-          if (VEC) {
-            v = *reinterpret_cast<const float4 *>(src);
-          } else {
-            v.x = src[0];
-            if (n + 1 < p.N) v.y = src[1];
-            if (n + 2 < p.N) v.z = src[2];
-            if (n + 3 < p.N) v.w = src[3];
-          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (n + e < p.N) v[e] = src[e];
         }
       }
-      rb[u] = v;
+      rb[u] = make_float4(v[0], v[1], v[2], v[3]);
     }
   };
   auto store_tiles = [&](int buf) {
@@ -253,20 +263,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  if (nkt > 0) {
-    load_a(kbeg);
-    load_b(kbeg);
-    store_tiles(0);
-  }
-  __syncthreads();
-
-  for (int kt = 0; kt < nkt; ++kt) {
-    const bool more = (kt + 1 < nkt);
-    if (more) {
-      load_a(kbeg + (kt + 1) * BK);
-      load_b(kbeg + (kt + 1) * BK);
-    }
-    const float *As = lds + (kt & 1) * (A_ELEMS + B_ELEMS);
+  // MFMAs of one K-tile out of LDS buffer `buf`
+  auto compute = [&](int buf) {
+    const float *As = lds + buf * (A_ELEMS + B_ELEMS);
     const float *Bs = As + A_ELEMS;
 #pragma unroll
     for (int g = 0; g < BK / 8; ++g) {
@@ -299,6 +298,34 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
           for (int q = 0; q < TN; ++q)
             acc[i][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][j], bf[q][j], acc[i][q], 0, 0, 0);
     }
+  };
+
+  // K-tiles completely inside the split take the fast loads; at most one tail tile does not.
+  const int nfull = VEC ? (kend - kbeg) / BK : 0;
+  if (nkt > 0) {
+    if (nfull > 0) load_fast(0); else load_slow(0);
+    store_tiles(0);
+  }
+  __syncthreads();
+
+  int kt = 0;
+  // steady state: prefetch tile kt+1 (global -> registers) under the MFMAs of tile kt, then
+  // registers -> the other LDS buffer; one barrier per tile, no branch inside
+  for (; kt + 1 < nfull; ++kt) {
+    load_fast(kt + 1);
+    // keep the loads up here: the scheduler would otherwise sink them next to their first use
+    // (the LDS store below) and expose the whole memory latency every tile
+    __builtin_amdgcn_sched_barrier(0);
+    compute(kt & 1);
+    __builtin_amdgcn_sched_barrier(0);
+    store_tiles((kt + 1) & 1);
+    __syncthreads();
+  }
+  // the last full tile and the tail tile (or everything, for unaligned operands)
+  for (; kt < nkt; ++kt) {
+    const bool more = (kt + 1 < nkt);
+    if (more) load_slow(kt + 1);
+    compute(kt & 1);
     if (more) store_tiles((kt + 1) & 1);
     __syncthreads();
   }
@@ -357,9 +384,10 @@ struct Plan {
 // Rough cycle model used to pick the tile and the split: MFMA time of the busiest CU, the
 // L2->LDS staging rate a CU sustains, a fixed prologue/epilogue cost per block, and the HBM
 // round trip of the partial slabs plus the extra launch when K is split.
+int force_bm = -1, force_bn = -1, force_s = -1;
+bool env_read = false;
+
 Plan make_plan(int M, int N, int K, int num_cu, bool allow_split) {
-  static int force_bm = -1, force_bn = -1, force_s = -1;
-  static bool env_read = false;
   if (!env_read) {
     env_read = true;
     const char *e = getenv("KALDI_HIP_GEMM_FORCE");  // "BM,BN,S" for experiments
@@ -657,6 +685,14 @@ KH_EXPORT int hipF_affine_apply(khStream_t s, int32_t O, int32_t I, const float 
   hipLaunchKernelGGL(bias_apply_kernel, dim3((O + 255) / 256), dim3(256), 0, st, O, bgrad, gscale, momentum, lr, bias,
                      bcorr);
   return kh::launch_status();
+}
+
+KH_EXPORT int hipK_gemm_force_plan(int bm, int bn, int splitk) {
+  env_read = true;
+  force_bm = bm > 0 ? bm : -1;
+  force_bn = bn > 0 ? bn : -1;
+  force_s = splitk > 0 ? splitk : -1;
+  return KH_OK;
 }
 
 KH_EXPORT int hipK_gemm_timing(int enable) {
