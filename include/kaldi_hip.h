@@ -83,6 +83,10 @@ int hipK_event_create(khEvent_t *ev);
 int hipK_event_destroy(khEvent_t ev);
 int hipK_event_record(khEvent_t ev, khStream_t s);
 int hipK_event_synchronize(khEvent_t ev); /* blocking */
+/* Work queued on `s` after this call starts only when everything recorded into `ev` has finished
+ * (no host blocking).  No counterpart in the reference, which used one stream: it orders the
+ * weight updates queued on a second stream against the backward pass. */
+int hipK_stream_wait_event(khStream_t s, khEvent_t ev);
 int hipK_event_elapsed_ms(float *ms, khEvent_t start, khEvent_t stop);
 
 /* cudaMallocPitch (cu-matrix-inl.h:108): rows x cols floats, row pitch rounded up so that every

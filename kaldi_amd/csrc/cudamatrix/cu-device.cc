@@ -19,7 +19,9 @@ void CuDevice::SelectGpuId(int32 gpu_id) {
   int dev = -1;
   CU_SAFE_CALL(hipK_active_device(&dev));
   active_gpu_id_ = dev;
-  CU_SAFE_CALL(hipK_default_stream(&stream_));
+  CU_SAFE_CALL(hipK_default_stream(&main_stream_));
+  stream_ = main_stream_;
+  side_stream_ = NULL;
   initialised_ = true;
   if (verbose_) {
     char arch[64];

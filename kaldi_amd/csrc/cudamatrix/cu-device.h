@@ -37,27 +37,61 @@ class CuDevice {
   void Profile(bool on) { profiling_ = on; }
   bool Profiling() const { return profiling_; }
   std::string GetFreeMemory();
+  /// The stream every CuMatrix / CuVector operation is queued on (the main stream, unless a
+  /// CuStreamScope has redirected the calling code to the side stream).
   khStream_t Stream() {
     EnsureInit();
     return stream_;
   }
+  khStream_t MainStream() {
+    EnsureInit();
+    return main_stream_;
+  }
+  /// A second stream for work that may run beside the main stream's (weight updates beside the
+  /// backward pass).  Whoever queues work there orders it against the main stream with events
+  /// and joins it back before returning; everything else only ever sees the main stream.
+  khStream_t SideStream() {
+    EnsureInit();
+    if (side_stream_ == NULL) CU_SAFE_CALL(hipK_stream_create(&side_stream_));
+    return side_stream_;
+  }
+  /// `waiter` continues only after everything queued on `done` so far has finished (no host wait).
+  void Order(khStream_t done, khStream_t waiter, khEvent_t *ev) {
+    if (*ev == NULL) CU_SAFE_CALL(hipK_event_create(ev));
+    CU_SAFE_CALL(hipK_event_record(*ev, done));
+    CU_SAFE_CALL(hipK_stream_wait_event(waiter, *ev));
+  }
   void Synchronize() {
     EnsureInit();
-    CU_SAFE_CALL(hipK_stream_synchronize(stream_));
+    CU_SAFE_CALL(hipK_stream_synchronize(main_stream_));
   }
   void EnsureInit() {
     if (!initialised_) SelectGpuId(requested_gpu_id_);
   }
 
  private:
-  CuDevice() : initialised_(false), requested_gpu_id_(-1), active_gpu_id_(-1), verbose_(true), profiling_(false), stream_(NULL) {}
+  friend class CuStreamScope;
+  CuDevice()
+      : initialised_(false), requested_gpu_id_(-1), active_gpu_id_(-1), verbose_(true), profiling_(false),
+        stream_(NULL), main_stream_(NULL), side_stream_(NULL) {}
   ~CuDevice() {}
   bool initialised_;
   int32 requested_gpu_id_, active_gpu_id_;
   bool verbose_, profiling_;
-  khStream_t stream_;
+  khStream_t stream_, main_stream_, side_stream_;
   std::map<std::string, double> profile_map_;
   KALDI_DISALLOW_COPY_AND_ASSIGN(CuDevice);
+};
+
+/// While alive, operations of the calling code are queued on `s` instead of the main stream.
+class CuStreamScope {
+ public:
+  explicit CuStreamScope(khStream_t s) : saved_(CuDevice::Instantiate().stream_) { CuDevice::Instantiate().stream_ = s; }
+  ~CuStreamScope() { CuDevice::Instantiate().stream_ = saved_; }
+
+ private:
+  khStream_t saved_;
+  KALDI_DISALLOW_COPY_AND_ASSIGN(CuStreamScope);
 };
 
 }  // namespace kaldi

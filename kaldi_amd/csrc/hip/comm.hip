@@ -103,7 +103,7 @@ KH_EXPORT int hipK_comm_barrier(khStream_t s) {
   if (c.nranks == 1) return hipK_stream_synchronize(s);
   if (!c.comm) return KH_ERR_NOT_INITIALISED;
   void *ws;
-  int rc = kh::ensure_workspace(256, &ws);
+  int rc = kh::ensure_workspace(kh::pick(s), 256, &ws);
   if (rc != KH_OK) return rc;
   KH_NCCL(ncclAllReduce(ws, ws, 1, ncclFloat32, ncclSum, c.comm, kh::pick(s)));
   return hipK_stream_synchronize(s);

@@ -12,14 +12,23 @@
 
 namespace kh {
 
-// Process-wide state: one GPU, one default stream, one scratch workspace.
+// Scratch memory of the kernels launched on one stream (split-K slabs, per-row partials).  One
+// per stream: work queued on two streams may run at the same time and must not share it.
+struct Workspace {
+  hipStream_t stream = nullptr;
+  void *ptr = nullptr;
+  size_t bytes = 0;
+};
+
+// Process-wide state: one GPU, one default stream, a scratch workspace per stream in use.
 struct Context {
   bool initialised = false;
   int device = -1;
   hipStream_t stream = nullptr;
   int num_cu = 0;
-  void *workspace = nullptr;
-  size_t workspace_bytes = 0;
+  static constexpr int kMaxWorkspaces = 8;
+  Workspace workspaces[kMaxWorkspaces];
+  int num_workspaces = 0;
   char last_msg[256] = {0};
 };
 Context &ctx();
@@ -27,8 +36,8 @@ Context &ctx();
 // Stream to launch on: the caller's, or the library default when it passed NULL.
 inline hipStream_t pick(khStream_t s) { return s ? (hipStream_t)s : ctx().stream; }
 
-// Grows the shared workspace to at least `bytes` (blocking when it has to reallocate).
-int ensure_workspace(size_t bytes, void **ptr);
+// The workspace of stream `st`, grown to at least `bytes` (blocking when it has to reallocate).
+int ensure_workspace(hipStream_t st, size_t bytes, void **ptr);
 
 inline int launch_status() {
   hipError_t e = hipGetLastError();

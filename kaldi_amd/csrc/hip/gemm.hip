@@ -20,6 +20,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <type_traits>
 #include <vector>
 
 #include "common.h"
@@ -59,7 +60,20 @@ struct GemmParams {
   int ldw;
   float lr, l2, mom;
   int act;
+#ifdef KH_GEMM_STAMPS
+  unsigned long long *stamps;
+#endif
 };
+
+#ifdef KH_GEMM_STAMPS
+// diagnostic build only: cycle stamps of wave 0 of every workgroup, 16 slots per workgroup
+#define KH_STAMP(i)                                                                     \
+  do {                                                                                  \
+    if (p.stamps && threadIdx.x == 0) p.stamps[(size_t)blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+#else
+#define KH_STAMP(i) do { } while (0)
+#endif
 
 template <int EPI>
 __device__ __forceinline__ void epi_store(const GemmParams &p, int row, int col, float acc, int ks) {
@@ -115,6 +129,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
   // ---- which tile: XCD-aware decode of the linear block id -----------------------------------
   // Blocks b and b+8 run on the same XCD (same L2); give each XCD a contiguous run of tiles so
   // that neighbours, which share the B (weight) panel, hit in that L2.
+  KH_STAMP(0);
   const int nblk = gridDim.x;
   int L = blockIdx.x;
   if ((nblk & 7) == 0) L = (L & 7) * (nblk >> 3) + (L >> 3);
@@ -263,73 +278,185 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  // MFMAs of one K-tile out of LDS buffer `buf`
+  // ---- operand fragments ------------------------------------------------------------------------
+  // One group = 8 k = 4 MFMA steps per accumulator.  A fragment is fetched by RN single LDS read
+  // instructions (one 16-byte read per 32-row block of a K-contiguous operand, four 4-byte reads
+  // otherwise), numbered so that the pipelined loop can place them one by one.
+  struct Frag {
+    float a[TM][4], b[TN][4];
+  };
+  constexpr int RN_A = A_KMAJOR ? TM : 4 * TM, RN_B = B_KMAJOR ? TN : 4 * TN, RN = RN_A + RN_B;
+  const int a_lds = A_KMAJOR ? (wm0 + li) * PA + lh * 4 : lh * 4 * PA + wm0 + li;
+  const int b_lds = A_ELEMS + (B_KMAJOR ? (wn0 + li) * PB + lh * 4 : lh * 4 * PB + wn0 + li);
+  auto read_op = [&](Frag &f, const float *base, int g, int r) {
+    if (r < RN_A) {
+      if (A_KMAJOR) {
+        const float4 t = *reinterpret_cast<const float4 *>(base + a_lds + r * 32 * PA + g * 8);
+        f.a[r][0] = t.x; f.a[r][1] = t.y; f.a[r][2] = t.z; f.a[r][3] = t.w;
+      } else {
+        f.a[r >> 2][r & 3] = base[a_lds + (g * 8 + (r & 3)) * PA + (r >> 2) * 32];
+      }
+    } else {
+      r -= RN_A;
+      if (B_KMAJOR) {
+        const float4 t = *reinterpret_cast<const float4 *>(base + b_lds + r * 32 * PB + g * 8);
+        f.b[r][0] = t.x; f.b[r][1] = t.y; f.b[r][2] = t.z; f.b[r][3] = t.w;
+      } else {
+        f.b[r >> 2][r & 3] = base[b_lds + (g * 8 + (r & 3)) * PB + (r >> 2) * 32];
+      }
+    }
+  };
+  // one register-staged 16-byte unit of the next tile: registers -> LDS, global -> registers
+  constexpr int NC = A_UNITS + B_UNITS;
+  auto write_op = [&](float *base, int c) {
+    if (c < A_UNITS) {
+      const int unit = tid + c * NT;
+      const int off = A_KMAJOR ? (unit / (BK / 4)) * PA + (unit % (BK / 4)) * 4 : (unit / (BM / 4)) * PA + (unit % (BM / 4)) * 4;
+      *reinterpret_cast<float4 *>(base + off) = ra[c];
+    } else {
+      const int unit = tid + (c - A_UNITS) * NT;
+      const int off = B_KMAJOR ? (unit / (BK / 4)) * PB + (unit % (BK / 4)) * 4 : (unit / (BN / 4)) * PB + (unit % (BN / 4)) * 4;
+      *reinterpret_cast<float4 *>(base + A_ELEMS + off) = rb[c - A_UNITS];
+    }
+  };
+  auto load_op = [&](int c, int kt) {
+    if (c < A_UNITS) ra[c] = *reinterpret_cast<const float4 *>(pa[c] + kt * a_step);
+    else rb[c - A_UNITS] = *reinterpret_cast<const float4 *>(pb[c - A_UNITS] + kt * b_step);
+  };
+  // MFMAs of one K-tile out of LDS buffer `buf`, unpipelined (K tail, unaligned operands)
   auto compute = [&](int buf) {
-    const float *As = lds + buf * (A_ELEMS + B_ELEMS);
-    const float *Bs = As + A_ELEMS;
+    const float *base = lds + buf * (A_ELEMS + B_ELEMS);
 #pragma unroll
     for (int g = 0; g < BK / 8; ++g) {
-      float af[TM][4], bf[TN][4];
+      Frag f;
 #pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        if (A_KMAJOR) {
-          const float4 t = *reinterpret_cast<const float4 *>(As + (wm0 + i * 32 + li) * PA + g * 8 + lh * 4);
-          af[i][0] = t.x; af[i][1] = t.y; af[i][2] = t.z; af[i][3] = t.w;
-        } else {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) af[i][j] = As[(g * 8 + lh * 4 + j) * PA + wm0 + i * 32 + li];
-        }
-      }
-#pragma unroll
-      for (int i = 0; i < TN; ++i) {
-        if (B_KMAJOR) {
-          const float4 t = *reinterpret_cast<const float4 *>(Bs + (wn0 + i * 32 + li) * PB + g * 8 + lh * 4);
-          bf[i][0] = t.x; bf[i][1] = t.y; bf[i][2] = t.z; bf[i][3] = t.w;
-        } else {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) bf[i][j] = Bs[(g * 8 + lh * 4 + j) * PB + wn0 + i * 32 + li];
-        }
-      }
+      for (int r = 0; r < RN; ++r) read_op(f, base, g, r);
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
           for (int q = 0; q < TN; ++q)
-            acc[i][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][j], bf[q][j], acc[i][q], 0, 0, 0);
+            acc[i][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[i][j], f.b[q][j], acc[i][q], 0, 0, 0);
     }
+  };
+  // Workgroup barrier that drains this wave's LDS traffic only: global loads issued for a later
+  // K-tile stay in flight across it (__syncthreads would wait for them too).
+  auto lds_barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+
+  // Epilogue operand fetched under the main loop (the weight tile of the update GEMM): one
+  // accumulator's worth per K-tile, so that the read-modify-write at the end starts with the old
+  // weights already in registers instead of every workgroup hitting HBM at the same moment.
+  constexpr bool PREFETCH = (EPI == EPI_UPDATE);
+  constexpr int NPRE = PREFETCH ? TM * TN : 1;
+  float pre[NPRE][16];
+  const bool full_tile = (m0 + BM <= p.M) && (n0 + BN <= p.N);
+  int npre = 0;  // accumulators whose operand is in `pre`
+  auto prefetch_acc = [&](int a) {
+    const int i = a / TN, q = a % TN;
+    const float *src = p.W + (size_t)(m0 + wm0 + i * 32 + 4 * lh) * p.ldw + (n0 + wn0 + q * 32 + li);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) pre[a][r] = src[(size_t)((r & 3) + 8 * (r >> 2)) * p.ldw];
   };
 
   // K-tiles completely inside the split take the fast loads; at most one tail tile does not.
   const int nfull = VEC ? (kend - kbeg) / BK : 0;
-  if (nkt > 0) {
-    if (nfull > 0) load_fast(0); else load_slow(0);
-    store_tiles(0);
-  }
-  __syncthreads();
-
+  constexpr int G = BK / 8;           // k-groups per tile
+  constexpr int MG = 4 * TM * TN;     // MFMAs per group
+  static_assert(G >= 4 && G % 2 == 0, "BK must be a multiple of 16, at least 32");
+  constexpr int RPS = (RN + (MG / 2) - 1) / (MG / 2);  // LDS reads per MFMA slot: done by mid-group
   int kt = 0;
-  // steady state: prefetch tile kt+1 (global -> registers) under the MFMAs of tile kt, then
-  // registers -> the other LDS buffer; one barrier per tile, no branch inside
-  for (; kt + 1 < nfull; ++kt) {
-    load_fast(kt + 1);
-    // keep the loads up here: the scheduler would otherwise sink them next to their first use
-    // (the LDS store below) and expose the whole memory latency every tile
-    __builtin_amdgcn_sched_barrier(0);
-    compute(kt & 1);
-    __builtin_amdgcn_sched_barrier(0);
-    store_tiles((kt + 1) & 1);
+  if (nfull == 0) {
+    // unaligned operands or a K range shorter than one tile: plain double-buffered loop
+    if (nkt > 0) {
+      load_slow(0);
+      store_tiles(0);
+    }
     __syncthreads();
-  }
-  // the last full tile and the tail tile (or everything, for unaligned operands)
-  for (; kt < nkt; ++kt) {
-    const bool more = (kt + 1 < nkt);
-    if (more) load_slow(kt + 1);
-    compute(kt & 1);
-    if (more) store_tiles((kt + 1) & 1);
+    for (; kt < nkt; ++kt) {
+      const bool more = (kt + 1 < nkt);
+      if (more) load_slow(kt + 1);
+      compute(kt & 1);
+      if (more) store_tiles((kt + 1) & 1);
+      __syncthreads();
+    }
+  } else {
+    // Software pipeline inside the wave (one wave per SIMD has nobody else to hide its latencies).
+    // Every MFMA is followed by at most a few memory instructions, pinned there with scheduling
+    // barriers so that they issue in the shadow of that MFMA:
+    //   * the LDS reads of k-group g+1 go behind the first MFMAs of group g;
+    //   * the next tile moves registers -> other LDS buffer unit by unit during groups 1..G-2,
+    //     each unit's global load for the tile after that re-issued right behind its LDS store,
+    //     i.e. a whole tile of MFMAs ahead of its use;
+    //   * the one barrier per tile follows the first MFMA of the last group, whose operands were
+    //     fetched before it; the reads behind it fetch group 0 of the next tile.
+    load_fast(0);
+    KH_STAMP(1);
+    store_tiles(0);
+    KH_STAMP(2);
     __syncthreads();
+    KH_STAMP(3);
+    if (nfull > 1) load_fast(1);
+    Frag fr[2];
+#pragma unroll
+    for (int r = 0; r < RN; ++r) read_op(fr[0], lds, 0, r);
+
+    auto tile_body = [&](auto last_tag) {
+      constexpr bool LAST = decltype(last_tag)::value;
+      float *cur = lds + (kt & 1) * (A_ELEMS + B_ELEMS);
+      float *nxt = lds + ((kt + 1) & 1) * (A_ELEMS + B_ELEMS);
+      const int kt_load = min(kt + 2, nfull - 1);  // past the end: a harmless repeat of the last tile
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+#pragma unroll
+        for (int t = 0; t < MG; ++t) {
+          const int j = t / (TM * TN), i = (t % (TM * TN)) / TN, q = t % TN;
+          acc[i][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(fr[g & 1].a[i][j], fr[g & 1].b[q][j], acc[i][q], 0, 0, 0);
+          if (g + 1 < G) {
+#pragma unroll
+            for (int r = 0; r < RN; ++r)
+              if (r / RPS == t) read_op(fr[(g + 1) & 1], cur, g + 1, r);
+          } else if (!LAST) {
+            if (t == 0) lds_barrier();
+#pragma unroll
+            for (int r = 0; r < RN; ++r)
+              if (r / RPS == t) read_op(fr[0], nxt, 0, r);
+          }
+          if (!LAST && g >= 1 && g <= G - 2) {
+#pragma unroll
+            for (int c = 0; c < NC; ++c)
+              if (MG + (c * MG * (G - 2)) / NC == g * MG + t) {
+                write_op(nxt, c);
+                load_op(c, kt_load);
+              }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    };
+    for (; kt + 1 < nfull; ++kt) {
+      if (PREFETCH && full_tile) {
+#pragma unroll
+        for (int a = 0; a < NPRE; ++a)
+          if (kt == a) {
+            prefetch_acc(a);
+            npre = a + 1;
+          }
+      }
+      tile_body(std::false_type());
+    }
+    KH_STAMP(4);
+    const bool tail = nkt > nfull;  // the K tail, at most one partial tile
+    if (tail) load_slow(nfull);
+    tile_body(std::true_type());
+    if (tail) {
+      store_tiles(nfull & 1);
+      __syncthreads();
+      compute(nfull & 1);
+    }
   }
 
+  KH_STAMP(5);
   // ---- epilogue: accumulator register r of lane (li, lh) is C[(r&3) + 8*(r>>2) + 4*lh][li] ------
 #pragma unroll
   for (int i = 0; i < TM; ++i)
@@ -339,8 +466,23 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
       for (int r = 0; r < 16; ++r) {
         const int row = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
         const int col = n0 + wn0 + q * 32 + li;
-        if (row < p.M && col < p.N) epi_store<EPI>(p, row, col, acc[i][q][r], ks);
+        if (PREFETCH && i * TN + q < npre) {
+          // full tile, old weight already here (same arithmetic as epi_store<EPI_UPDATE>)
+          float c = p.alpha * acc[i][q][r];
+          if (p.mom != 0.f) c += p.mom * p.C[(size_t)row * p.ldc + col];
+          if (p.C) p.C[(size_t)row * p.ldc + col] = c;
+          float wv = pre[PREFETCH ? i * TN + q : 0][r];
+          if (p.l2 != 0.f) wv = -p.l2 * wv + wv;
+          p.W[(size_t)row * p.ldw + col] = -p.lr * c + wv;
+        } else if (row < p.M && col < p.N) {
+          epi_store<EPI>(p, row, col, acc[i][q][r], ks);
+        }
       }
+  KH_STAMP(6);
+#ifdef KH_GEMM_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  KH_STAMP(7);
+#endif
 }
 
 // ---- sum of split-K slabs + the element-wise step that follows the GEMM ------------------------
@@ -532,7 +674,7 @@ int run_gemm(khStream_t s, bool a_kmajor, bool b_kmajor, GemmParams p, bool allo
   const int ld_slab = (p.N + 3) & ~3;
   const size_t slab_stride = (size_t)p.M * ld_slab;
   void *ws;
-  int rc = kh::ensure_workspace(slab_stride * p.splitk * sizeof(float), &ws);
+  int rc = kh::ensure_workspace(st, slab_stride * p.splitk * sizeof(float), &ws);
   if (rc != KH_OK) return rc;
   GemmParams ps = p;
   ps.C = (float *)ws;
@@ -552,6 +694,11 @@ int run_gemm(khStream_t s, bool a_kmajor, bool b_kmajor, GemmParams p, bool allo
   return kh::launch_status();
 }
 
+#ifdef KH_GEMM_STAMPS
+unsigned long long *g_stamps = nullptr;
+constexpr size_t kStampSlots = 16 * 65536;
+#endif
+
 GemmParams base_params(int M, int N, int K, const float *A, int lda, const float *B, int ldb, float *C, int ldc) {
   GemmParams p;
   memset(&p, 0, sizeof(p));
@@ -559,6 +706,10 @@ GemmParams base_params(int M, int N, int K, const float *A, int lda, const float
   p.M = M; p.N = N; p.K = K;
   p.C = C; p.ldc = ldc;
   p.alpha = 1.f; p.beta = 0.f;
+#ifdef KH_GEMM_STAMPS
+  if (!g_stamps && hipMalloc((void **)&g_stamps, kStampSlots * 8) != hipSuccess) g_stamps = nullptr;
+  p.stamps = g_stamps;
+#endif
   return p;
 }
 
@@ -686,6 +837,16 @@ KH_EXPORT int hipF_affine_apply(khStream_t s, int32_t O, int32_t I, const float 
                      bcorr);
   return kh::launch_status();
 }
+
+#ifdef KH_GEMM_STAMPS
+// diagnostic build only: copies the stamps of the last GEMM launch (16 per workgroup) to the host
+KH_EXPORT int hipK_gemm_stamps_read(unsigned long long *dst, size_t slots) {
+  KH_REQUIRE(dst && slots <= kStampSlots && g_stamps);
+  KH_HIP(hipDeviceSynchronize());
+  KH_HIP(hipMemcpy(dst, g_stamps, slots * 8, hipMemcpyDeviceToHost));
+  return KH_OK;
+}
+#endif
 
 KH_EXPORT int hipK_gemm_force_plan(int bm, int bn, int splitk) {
   env_read = true;

@@ -352,7 +352,7 @@ KH_EXPORT int hipF_xent_eval(khStream_t s, const float *post, const int32_t *tgt
   int32_t *mi = max_id;
   if (!lp || !mi) {
     void *ws;
-    int st = kh::ensure_workspace((size_t)d.rows * 8, &ws);
+    int st = kh::ensure_workspace(kh::pick(s), (size_t)d.rows * 8, &ws);
     if (st != KH_OK) return st;
     if (!lp) lp = (float *)ws;
     if (!mi) mi = (int32_t *)((char *)ws + (size_t)d.rows * 4);
@@ -372,7 +372,7 @@ KH_EXPORT int hipF_mse_eval(khStream_t s, const float *a, const float *b, float 
   float *rs = row_sq;
   if (!rs) {
     void *ws;
-    int st = kh::ensure_workspace((size_t)d.rows * 4, &ws);
+    int st = kh::ensure_workspace(kh::pick(s), (size_t)d.rows * 4, &ws);
     if (st != KH_OK) return st;
     rs = (float *)ws;
   }

@@ -11,20 +11,41 @@ Context &ctx() {
   return c;
 }
 
-int ensure_workspace(size_t bytes, void **ptr) {
+int ensure_workspace(hipStream_t st, size_t bytes, void **ptr) {
   Context &c = ctx();
-  if (bytes > c.workspace_bytes) {
+  Workspace *w = nullptr;
+  for (int i = 0; i < c.num_workspaces; ++i)
+    if (c.workspaces[i].stream == st) w = &c.workspaces[i];
+  if (!w) {
+    if (c.num_workspaces == Context::kMaxWorkspaces) {
+      snprintf(c.last_msg, sizeof(c.last_msg), "more than %d streams use library scratch memory", Context::kMaxWorkspaces);
+      return KH_ERR_TOO_LARGE;
+    }
+    w = &c.workspaces[c.num_workspaces++];
+    w->stream = st;
+  }
+  if (bytes > w->bytes) {
     // Allocation churn is what this avoids: round up generously, reallocate rarely.
     size_t want = bytes + bytes / 4;
     want = (want + ((size_t)1 << 20) - 1) & ~(((size_t)1 << 20) - 1);
     KH_HIP(hipDeviceSynchronize());
-    if (c.workspace) KH_HIP(hipFree(c.workspace));
-    c.workspace = nullptr;
-    c.workspace_bytes = 0;
-    KH_HIP(hipMalloc(&c.workspace, want));
-    c.workspace_bytes = want;
+    if (w->ptr) KH_HIP(hipFree(w->ptr));
+    w->ptr = nullptr;
+    w->bytes = 0;
+    KH_HIP(hipMalloc(&w->ptr, want));
+    w->bytes = want;
   }
-  *ptr = c.workspace;
+  *ptr = w->ptr;
+  return KH_OK;
+}
+
+static int free_workspaces() {
+  Context &c = ctx();
+  for (int i = 0; i < c.num_workspaces; ++i) {
+    if (c.workspaces[i].ptr) KH_HIP(hipFree(c.workspaces[i].ptr));
+    c.workspaces[i] = Workspace();
+  }
+  c.num_workspaces = 0;
   return KH_OK;
 }
 
@@ -85,9 +106,8 @@ KH_EXPORT int hipK_shutdown(void) {
   kh::Context &c = ctx();
   if (!c.initialised) return KH_OK;
   KH_HIP(hipDeviceSynchronize());
-  if (c.workspace) KH_HIP(hipFree(c.workspace));
-  c.workspace = nullptr;
-  c.workspace_bytes = 0;
+  int st = kh::free_workspaces();
+  if (st != KH_OK) return st;
   if (c.stream) KH_HIP(hipStreamDestroy(c.stream));
   c.stream = nullptr;
   c.initialised = false;
@@ -126,6 +146,15 @@ KH_EXPORT int hipK_stream_create(khStream_t *stream) {
 
 KH_EXPORT int hipK_stream_destroy(khStream_t stream) {
   KH_REQUIRE(stream != nullptr);
+  KH_HIP(hipStreamSynchronize((hipStream_t)stream));
+  kh::Context &c = ctx();
+  for (int i = 0; i < c.num_workspaces; ++i)
+    if (c.workspaces[i].stream == (hipStream_t)stream) {
+      if (c.workspaces[i].ptr) KH_HIP(hipFree(c.workspaces[i].ptr));
+      c.workspaces[i] = c.workspaces[--c.num_workspaces];
+      c.workspaces[c.num_workspaces] = kh::Workspace();
+      break;
+    }
   KH_HIP(hipStreamDestroy((hipStream_t)stream));
   return KH_OK;
 }
@@ -133,6 +162,13 @@ KH_EXPORT int hipK_stream_destroy(khStream_t stream) {
 KH_EXPORT int hipK_stream_synchronize(khStream_t stream) {
   KH_CHECK_INIT();
   KH_HIP(hipStreamSynchronize(kh::pick(stream)));
+  return KH_OK;
+}
+
+KH_EXPORT int hipK_stream_wait_event(khStream_t stream, khEvent_t ev) {
+  KH_CHECK_INIT();
+  KH_REQUIRE(ev != nullptr);
+  KH_HIP(hipStreamWaitEvent(kh::pick(stream), (hipEvent_t)ev, 0));
   return KH_OK;
 }
 
@@ -275,5 +311,5 @@ KH_EXPORT int hipK_event_elapsed_ms(float *ms, khEvent_t start, khEvent_t stop) 
 KH_EXPORT int hipK_reserve_workspace(size_t bytes) {
   KH_CHECK_INIT();
   void *p;
-  return kh::ensure_workspace(bytes, &p);
+  return kh::ensure_workspace(kh::ctx().stream, bytes, &p);
 }

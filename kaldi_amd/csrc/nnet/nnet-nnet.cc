@@ -12,6 +12,9 @@ namespace kaldi {
 Nnet::~Nnet() {
   for (size_t i = 0; i < nnet_.size(); ++i) delete nnet_[i];
   if (dp_grad_) hipK_free(dp_grad_);
+  for (size_t i = 0; i < layer_events_.size(); ++i)
+    if (layer_events_[i]) hipK_event_destroy(layer_events_[i]);
+  if (join_event_) hipK_event_destroy(join_event_);
 }
 
 MatrixIndexT Nnet::InputDim() const {
@@ -102,6 +105,26 @@ void Nnet::Backpropagate(const CuMatrix<BaseFloat> &in_err, CuMatrix<BaseFloat> 
   KALDI_ASSERT(static_cast<int32>(propagate_buf_.size()) >= L + 1);
   KALDI_ASSERT(static_cast<int32>(backpropagate_buf_.size()) >= L - 1);
 
+  // Two queues.  The main stream carries the chain of error back-propagations; a layer's update
+  // needs only its input, its output error and that nobody still reads the old weights, so it is
+  // queued on the side stream behind an event recorded right after that layer's own
+  // back-propagation, and runs beside the back-propagation of the layers below.  The side stream
+  // is joined back before returning, so callers keep seeing one in-order stream.
+  CuDevice &dev = CuDevice::Instantiate();
+  const bool overlap = overlap_ && !dev.Profiling();
+  if (overlap && static_cast<int32>(layer_events_.size()) < L) layer_events_.resize(L, NULL);
+  bool side_used = false;
+  auto update = [&](int32 i, const CuMatrix<BaseFloat> &input, const CuMatrix<BaseFloat> &err) {
+    if (!overlap || !nnet_[i]->IsUpdatable()) {
+      UpdateLayer(i, input, err);
+      return;
+    }
+    dev.Order(dev.MainStream(), dev.SideStream(), &layer_events_[i]);
+    CuStreamScope scope(dev.SideStream());
+    UpdateLayer(i, input, err);
+    side_used = true;
+  };
+
   const CuMatrix<BaseFloat> *err = &in_err;  // error w.r.t. the output of layer i
   int32 i = L - 1;
   while (i >= 0) {
@@ -119,16 +142,17 @@ void Nnet::Backpropagate(const CuMatrix<BaseFloat> &in_err, CuMatrix<BaseFloat> 
       BiasedLinearity *bl = static_cast<BiasedLinearity *>(comp);
       CuMatrix<BaseFloat> *below2 = (i - 1 > 0) ? &backpropagate_buf_[i - 2] : out_err;
       if (below2 != NULL) bl->BackpropagateFused(*err, propagate_buf_[i], below2);
-      UpdateLayer(i, propagate_buf_[i], *err);
+      update(i, propagate_buf_[i], *err);
       err = below2;
       i -= 2;
       continue;
     }
     if (below != NULL) comp->Backpropagate(*err, below);
-    UpdateLayer(i, propagate_buf_[i], *err);
+    update(i, propagate_buf_[i], *err);
     err = below;
     --i;
   }
+  if (side_used) dev.Order(dev.SideStream(), dev.MainStream(), &join_event_);
 }
 
 void Nnet::Feedforward(const CuMatrix<BaseFloat> &in, CuMatrix<BaseFloat> *out) {

@@ -26,7 +26,7 @@ namespace kaldi {
 
 class Nnet {
  public:
-  Nnet() : learn_rate_(0.0), fusion_(true), dp_ranks_(1), dp_grad_(NULL), dp_grad_size_(0) {}
+  Nnet() : learn_rate_(0.0), fusion_(true), overlap_(true), dp_ranks_(1), dp_grad_(NULL), dp_grad_size_(0), join_event_(NULL) {}
   ~Nnet();
 
   /// forward pass, keeping every layer's output for Backpropagate
@@ -63,6 +63,10 @@ class Nnet {
 
   /// fused forward/backward for the sigmoid-DNN pattern (on by default)
   void SetFusion(bool on) { fusion_ = on; }
+  /// Queue each layer's parameter update (and, data-parallel, its gradient all-reduce) on a second
+  /// stream so that it runs beside the backward pass of the layers below (on by default; the
+  /// arithmetic and its order inside every layer are unchanged).
+  void SetOverlapUpdates(bool on) { overlap_ = on; }
   /// Synchronous data-parallel training over `nranks` processes (one GPU each, communicator set up
   /// with hipK_comm_init): every <biasedlinearity> update becomes gradient -> sum all-reduce ->
   /// identical step on every rank, equal to one process training on the concatenated bunch.
@@ -76,10 +80,12 @@ class Nnet {
   std::vector<CuMatrix<BaseFloat> > propagate_buf_;
   std::vector<CuMatrix<BaseFloat> > backpropagate_buf_;
   BaseFloat learn_rate_;
-  bool fusion_;
+  bool fusion_, overlap_;
   int32 dp_ranks_;
   BaseFloat *dp_grad_;   // device staging buffer for one layer's gradient
   size_t dp_grad_size_;
+  std::vector<khEvent_t> layer_events_;  // "error of layer i ready, its weights no longer read"
+  khEvent_t join_event_;
   KALDI_DISALLOW_COPY_AND_ASSIGN(Nnet);
 };
 

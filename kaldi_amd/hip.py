@@ -11,7 +11,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(_HERE)
-LIB_PATH = os.path.join(_HERE, "lib", "libkaldi_hip.so")
+LIB_PATH = os.environ.get("KALDI_AMD_HIP_LIB") or os.path.join(_HERE, "lib", "libkaldi_hip.so")  # override: diagnostic builds
 HEADER_PATH = os.path.join(ROOT, "include", "kaldi_hip.h")
 
 NO_TRANS, TRANS = 111, 112
