@@ -269,6 +269,20 @@ int hipF_affine_update(khStream_t s, int32_t N, int32_t O, int32_t I, const floa
                        const float *in, int32_t ldin, float gscale, float momentum, float lr, float l2,
                        float *W, int32_t ldw, float *corr, int32_t ldcorr, float *bias, float *bcorr);
 
+/* The two halves of hipF_affine_update on their own, so that a caller can queue them on different
+ * streams (the bias half reads only e; the weight half reads only e and in besides W):
+ *   weights: corr = gscale * e^T * in + momentum * corr ; W_out = (1 - l2) * W_in - lr * corr
+ *   bias   : bcorr = gscale * colsum(e) + momentum * bcorr ; b = b - lr * bcorr
+ * W_out may be W_in (in place) or a second O x I buffer: reading the old weights from one buffer
+ * and writing the new ones to another lets the step run while other work still reads the old
+ * weights (the reference updates in place, nnet-biasedlinearity.h:95-101; the values are the same). */
+int hipF_affine_update_weights(khStream_t s, int32_t N, int32_t O, int32_t I, const float *e, int32_t lde,
+                               const float *in, int32_t ldin, float gscale, float momentum, float lr, float l2,
+                               const float *W_in, int32_t ldw_in, float *W_out, int32_t ldw_out, float *corr,
+                               int32_t ldcorr);
+int hipF_affine_update_bias(khStream_t s, int32_t N, int32_t O, const float *e, int32_t lde, float gscale,
+                            float momentum, float lr, float *bias, float *bcorr);
+
 /* Data-parallel form of the update, second half (the first half is a plain hipF_gemm into a dense
  * gradient buffer plus hipF_add_row_sum_mat, all-reduced across ranks by the caller):
  *   corr = gscale * grad + momentum * corr ;  W = (1 - l2) * W - lr * corr      (grad OxI, ld ldg)

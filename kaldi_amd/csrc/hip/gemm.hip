@@ -56,8 +56,10 @@ struct GemmParams {
   const float *bias;
   const float *y;
   int ldy;
-  float *W;
+  const float *W;  // weights read by the update epilogues ...
   int ldw;
+  float *Wout;     // ... and where the new ones go (may alias W)
+  int ldwout;
   float lr, l2, mom;
   int act;
 #ifdef KH_GEMM_STAMPS
@@ -93,18 +95,16 @@ __device__ __forceinline__ void epi_store(const GemmParams &p, int row, int col,
     float c = p.alpha * acc;
     if (p.mom != 0.f) c += p.mom * p.C[(size_t)row * p.ldc + col];
     if (p.C) p.C[(size_t)row * p.ldc + col] = c;
-    float *w = p.W + (size_t)row * p.ldw + col;
-    float wv = *w;
+    float wv = p.W[(size_t)row * p.ldw + col];
     if (p.l2 != 0.f) wv = -p.l2 * wv + wv;
-    *w = -p.lr * c + wv;
+    p.Wout[(size_t)row * p.ldwout + col] = -p.lr * c + wv;
   } else if (EPI == EPI_RBM) {
-    float *w = p.W + (size_t)row * p.ldw + col;
     float *dw = p.C + (size_t)row * p.ldc + col;
-    const float wv = *w;
+    const float wv = p.W[(size_t)row * p.ldw + col];
     float d = p.alpha * acc + *dw;
     d = -p.l2 * wv + d;
     *dw = d;
-    *w = d + wv;
+    p.Wout[(size_t)row * p.ldwout + col] = d + wv;
   }
 }
 
@@ -308,15 +308,23 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
   };
   // one register-staged 16-byte unit of the next tile: registers -> LDS, global -> registers
   constexpr int NC = A_UNITS + B_UNITS;
+  // 16 bytes into LDS as two 8-byte stores: measured beside dependent MFMAs, a ds_write_b128 into
+  // the padded image holds the wave ~59 cycles, the pair of ds_write_b64 ~1
+  auto lds_store16 = [&](float *dst, const float4 &v) {
+    *reinterpret_cast<float2 *>(dst) = make_float2(v.x, v.y);
+    *reinterpret_cast<float2 *>(dst + 2) = make_float2(v.z, v.w);
+  };
   auto write_op = [&](float *base, int c) {
     if (c < A_UNITS) {
       const int unit = tid + c * NT;
       const int off = A_KMAJOR ? (unit / (BK / 4)) * PA + (unit % (BK / 4)) * 4 : (unit / (BM / 4)) * PA + (unit % (BM / 4)) * 4;
-      *reinterpret_cast<float4 *>(base + off) = ra[c];
+      if (A_KMAJOR) lds_store16(base + off, ra[c]);
+      else *reinterpret_cast<float4 *>(base + off) = ra[c];
     } else {
       const int unit = tid + (c - A_UNITS) * NT;
       const int off = B_KMAJOR ? (unit / (BK / 4)) * PB + (unit % (BK / 4)) * 4 : (unit / (BN / 4)) * PB + (unit % (BN / 4)) * 4;
-      *reinterpret_cast<float4 *>(base + A_ELEMS + off) = rb[c - A_UNITS];
+      if (B_KMAJOR) lds_store16(base + A_ELEMS + off, rb[c - A_UNITS]);
+      else *reinterpret_cast<float4 *>(base + A_ELEMS + off) = rb[c - A_UNITS];
     }
   };
   auto load_op = [&](int c, int kt) {
@@ -473,7 +481,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
           if (p.C) p.C[(size_t)row * p.ldc + col] = c;
           float wv = pre[PREFETCH ? i * TN + q : 0][r];
           if (p.l2 != 0.f) wv = -p.l2 * wv + wv;
-          p.W[(size_t)row * p.ldw + col] = -p.lr * c + wv;
+          p.Wout[(size_t)row * p.ldwout + col] = -p.lr * c + wv;
         } else if (row < p.M && col < p.N) {
           epi_store<EPI>(p, row, col, acc[i][q][r], ks);
         }
@@ -931,27 +939,46 @@ KH_EXPORT int hipF_affine_backward(khStream_t s, int32_t N, int32_t O, int32_t I
   return run_gemm<EPI_AXPBY>(s, true, false, p, true);
 }
 
-KH_EXPORT int hipF_affine_update(khStream_t s, int32_t N, int32_t O, int32_t I, const float *e, int32_t lde,
-                                 const float *in, int32_t ldin, float gscale, float momentum, float lr, float l2,
-                                 float *W, int32_t ldw, float *corr, int32_t ldcorr, float *bias, float *bcorr) {
+KH_EXPORT int hipF_affine_update_weights(khStream_t s, int32_t N, int32_t O, int32_t I, const float *e, int32_t lde,
+                                         const float *in, int32_t ldin, float gscale, float momentum, float lr,
+                                         float l2, const float *W_in, int32_t ldw_in, float *W_out, int32_t ldw_out,
+                                         float *corr, int32_t ldcorr) {
   KH_CHECK_INIT();
   KH_REQUIRE(N > 0 && O > 0 && I > 0);
-  KH_REQUIRE(e && in && W && bias && lde >= O && ldin >= I && ldw >= I);
-  KH_REQUIRE(momentum == 0.f || (corr != nullptr && bcorr != nullptr));
+  KH_REQUIRE(e && in && W_in && W_out && lde >= O && ldin >= I && ldw_in >= I && ldw_out >= I);
+  KH_REQUIRE(momentum == 0.f || corr != nullptr);
   KH_REQUIRE(corr == nullptr || ldcorr >= I);
-  // weights: corr(OxI) = g * e^T(OxN) * in(NxI) + mom*corr, W updated in the same epilogue
+  // corr(OxI) = g * e^T(OxN) * in(NxI) + mom*corr, the weight step in the same epilogue
   GemmParams p = base_params(O, I, N, e, lde, in, ldin, corr, ldcorr);
   p.alpha = gscale;
   p.mom = momentum;
   p.lr = lr;
   p.l2 = l2;
-  p.W = W;
-  p.ldw = ldw;
-  int rc = run_gemm<EPI_UPDATE>(s, false, false, p, /*allow_split=*/false);
-  if (rc != KH_OK) return rc;
+  p.W = W_in;
+  p.ldw = ldw_in;
+  p.Wout = W_out;
+  p.ldwout = ldw_out;
+  return run_gemm<EPI_UPDATE>(s, false, false, p, /*allow_split=*/false);
+}
+
+KH_EXPORT int hipF_affine_update_bias(khStream_t s, int32_t N, int32_t O, const float *e, int32_t lde, float gscale,
+                                      float momentum, float lr, float *bias, float *bcorr) {
+  KH_CHECK_INIT();
+  KH_REQUIRE(N > 0 && O > 0 && e && bias && lde >= O);
+  KH_REQUIRE(momentum == 0.f || bcorr != nullptr);
   hipLaunchKernelGGL(bias_update_kernel, dim3((O + 63) / 64), dim3(1024), 0, kh::pick(s), e, lde, N, O, gscale,
                      momentum, lr, bias, bcorr);
   return kh::launch_status();
+}
+
+KH_EXPORT int hipF_affine_update(khStream_t s, int32_t N, int32_t O, int32_t I, const float *e, int32_t lde,
+                                 const float *in, int32_t ldin, float gscale, float momentum, float lr, float l2,
+                                 float *W, int32_t ldw, float *corr, int32_t ldcorr, float *bias, float *bcorr) {
+  KH_REQUIRE(momentum == 0.f || (corr != nullptr && bcorr != nullptr));
+  int rc = hipF_affine_update_weights(s, N, O, I, e, lde, in, ldin, gscale, momentum, lr, l2, W, ldw, W, ldw, corr,
+                                      ldcorr);
+  if (rc != KH_OK) return rc;
+  return hipF_affine_update_bias(s, N, O, e, lde, gscale, momentum, lr, bias, bcorr);
 }
 
 KH_EXPORT int hipF_rbm_update(khStream_t s, int32_t N, int32_t H, int32_t V, const float *pos_vis, int32_t ldpv,
@@ -976,6 +1003,8 @@ KH_EXPORT int hipF_rbm_update(khStream_t s, int32_t N, int32_t H, int32_t V, con
   p2.l2 = lr * l2;
   p2.W = W;
   p2.ldw = ldw;
+  p2.Wout = W;
+  p2.ldwout = ldw;
   rc = run_gemm<EPI_RBM>(s, false, false, p2, false);
   if (rc != KH_OK) return rc;
   hipStream_t st = kh::pick(s);

@@ -59,6 +59,20 @@ class BiasedLinearity : public UpdatableComponent {
   }
 
   void Update(const CuMatrix<BaseFloat> &input, const CuMatrix<BaseFloat> &err) {
+    UpdateWeights(input, err);
+    UpdateBias(err);
+  }
+
+  /// True when the two halves below are independent: the weight half then reads only `input`,
+  /// `err` and the old weights, the bias half only `err`, and they may be queued on different
+  /// streams.  (With an L1 penalty the reference's pass order is kept and everything happens in
+  /// UpdateWeights.)
+  bool SplitUpdate() const { return l1_penalty_ == 0.0; }
+
+  /// Weight half of Update.  With SetDoubleBuffer(true) the new weights are written to a second
+  /// buffer, which then becomes the component's weight matrix: work queued earlier keeps reading
+  /// the old values from the old buffer while this step runs.
+  void UpdateWeights(const CuMatrix<BaseFloat> &input, const CuMatrix<BaseFloat> &err) {
     CuProfileScope p("BiasedLinearity::Update");
     const int32 n = input.NumRows();
     KALDI_ASSERT(err.NumRows() == n && err.NumCols() == output_dim_ && input.NumCols() == input_dim_);
@@ -66,10 +80,17 @@ class BiasedLinearity : public UpdatableComponent {
     const BaseFloat l2 = (l2_penalty_ != 0.0) ? learn_rate_ * l2_penalty_ * n : 0.0;
     if (l1_penalty_ == 0.0) {
       // gradient GEMM with the momentum / weight-decay / SGD step in its epilogue
-      CU_SAFE_CALL(hipF_affine_update(S(), n, output_dim_, input_dim_, err.Data(), err.Stride(), input.Data(),
-                                      input.Stride(), gscale, momentum_, learn_rate_, l2, linearity_.Data(),
-                                      linearity_.Stride(), KeepCorr() ? linearity_corr_.Data() : NULL,
-                                      linearity_corr_.Stride(), bias_.Data(), KeepCorr() ? bias_corr_.Data() : NULL));
+      CuMatrix<BaseFloat> *dst = &linearity_;
+      if (double_buffer_) {
+        if (linearity_next_.NumRows() != output_dim_ || linearity_next_.NumCols() != input_dim_)
+          linearity_next_.Resize(output_dim_, input_dim_);
+        dst = &linearity_next_;
+      }
+      CU_SAFE_CALL(hipF_affine_update_weights(S(), n, output_dim_, input_dim_, err.Data(), err.Stride(), input.Data(),
+                                              input.Stride(), gscale, momentum_, learn_rate_, l2, linearity_.Data(),
+                                              linearity_.Stride(), dst->Data(), dst->Stride(),
+                                              KeepCorr() ? linearity_corr_.Data() : NULL, linearity_corr_.Stride()));
+      if (double_buffer_) linearity_.Swap(&linearity_next_);
     } else {
       // the L1 shrink sits between the gradient and the step, so the passes stay separate
       linearity_corr_.AddMatMat(gscale, err, kTrans, input, kNoTrans, momentum_);
@@ -82,6 +103,17 @@ class BiasedLinearity : public UpdatableComponent {
     }
     if (l2_upper_bound_ > 0.0) linearity_.ApplyRowL2UpperBound(l2_upper_bound_);
   }
+  /// Bias half of Update (nothing to do when UpdateWeights has handled the bias: L1 path).
+  void UpdateBias(const CuMatrix<BaseFloat> &err) {
+    if (l1_penalty_ != 0.0) return;
+    const int32 n = err.NumRows();
+    const BaseFloat gscale = average_grad_ ? 1.0 / n : 1.0;
+    CU_SAFE_CALL(hipF_affine_update_bias(S(), n, output_dim_, err.Data(), err.Stride(), gscale, momentum_, learn_rate_,
+                                         bias_.Data(), KeepCorr() ? bias_corr_.Data() : NULL));
+  }
+  void SetDoubleBuffer(bool on) { double_buffer_ = on; }
+  /// True when UpdateWeights leaves the buffer that earlier work reads untouched.
+  bool UpdateKeepsOldWeights() const { return double_buffer_ && l1_penalty_ == 0.0; }
 
   /// Data-parallel form of Update, first half: the raw sums  gW = err^T * input  and
   /// gb = colsum(err)  into one contiguous buffer [gW (dim_out x dim_in, dense) | gb].
@@ -159,7 +191,9 @@ class BiasedLinearity : public UpdatableComponent {
   CuVector<BaseFloat> bias_;
   CuMatrix<BaseFloat> linearity_corr_;
   CuVector<BaseFloat> bias_corr_;
+  CuMatrix<BaseFloat> linearity_next_;  // second weight buffer (SetDoubleBuffer)
   bool keep_gradient_ = false;
+  bool double_buffer_ = false;
 };
 
 }  // namespace kaldi

@@ -72,6 +72,25 @@ void Nnet::Propagate(const CuMatrix<BaseFloat> &in, CuMatrix<BaseFloat> *out) {
   }
 }
 
+void Nnet::DataParallelGradient(int32 i, BiasedLinearity *bl, const CuMatrix<BaseFloat> &input,
+                                const CuMatrix<BaseFloat> &err) {
+  // one staging buffer for all layers: the queue that uses it is in order, so a layer's step has
+  // consumed it before the next layer's gradient overwrites it
+  const size_t need = bl->GradientSize();
+  if (need > dp_grad_size_) {
+    if (dp_grad_) {
+      CU_SAFE_CALL(hipK_device_synchronize());
+      CU_SAFE_CALL(hipK_free(dp_grad_));
+    }
+    void *p = NULL;
+    CU_SAFE_CALL(hipK_malloc(&p, need * sizeof(BaseFloat)));
+    dp_grad_ = static_cast<BaseFloat *>(p);
+    dp_grad_size_ = need;
+  }
+  bl->ComputeGradient(input, err, dp_grad_);
+  CU_SAFE_CALL(hipF_allreduce_sum(CuDevice::Instantiate().Stream(), dp_grad_, need));
+}
+
 void Nnet::UpdateLayer(int32 i, const CuMatrix<BaseFloat> &input, const CuMatrix<BaseFloat> &err) {
   if (!nnet_[i]->IsUpdatable()) return;
   UpdatableComponent *uc = dynamic_cast<UpdatableComponent *>(nnet_[i]);
@@ -80,19 +99,7 @@ void Nnet::UpdateLayer(int32 i, const CuMatrix<BaseFloat> &input, const CuMatrix
     if (nnet_[i]->GetType() != Component::kBiasedLinearity)
       KALDI_ERR << "Data-parallel training supports <biasedlinearity> layers only";
     BiasedLinearity *bl = static_cast<BiasedLinearity *>(nnet_[i]);
-    const size_t need = bl->GradientSize();
-    if (need > dp_grad_size_) {
-      if (dp_grad_) {
-        CuDevice::Instantiate().Synchronize();
-        CU_SAFE_CALL(hipK_free(dp_grad_));
-      }
-      void *p = NULL;
-      CU_SAFE_CALL(hipK_malloc(&p, need * sizeof(BaseFloat)));
-      dp_grad_ = static_cast<BaseFloat *>(p);
-      dp_grad_size_ = need;
-    }
-    bl->ComputeGradient(input, err, dp_grad_);
-    CU_SAFE_CALL(hipF_allreduce_sum(CuDevice::Instantiate().Stream(), dp_grad_, need));
+    DataParallelGradient(i, bl, input, err);
     bl->ApplyGradient(dp_grad_, input.NumRows() * dp_ranks_);
   } else {
     uc->Update(input, err);
@@ -105,24 +112,55 @@ void Nnet::Backpropagate(const CuMatrix<BaseFloat> &in_err, CuMatrix<BaseFloat> 
   KALDI_ASSERT(static_cast<int32>(propagate_buf_.size()) >= L + 1);
   KALDI_ASSERT(static_cast<int32>(backpropagate_buf_.size()) >= L - 1);
 
-  // Two queues.  The main stream carries the chain of error back-propagations; a layer's update
-  // needs only its input, its output error and that nobody still reads the old weights, so it is
-  // queued on the side stream behind an event recorded right after that layer's own
-  // back-propagation, and runs beside the back-propagation of the layers below.  The side stream
-  // is joined back before returning, so callers keep seeing one in-order stream.
+  // Two queues.  The main stream carries the chain of error back-propagations and the (small)
+  // bias updates; a layer's weight update needs only its input, its output error and the old
+  // weights, so it is queued on the side stream and runs beside the back-propagation of this
+  // layer and of those below.  A <biasedlinearity> writes its new weights to a second buffer, so
+  // its update waits only for the error (event recorded before the layer's own
+  // back-propagation is queued); any other update waits until that back-propagation has read the
+  // weights.  The side stream is joined back before returning: callers keep seeing one in-order
+  // stream.
   CuDevice &dev = CuDevice::Instantiate();
   const bool overlap = overlap_ && !dev.Profiling();
   if (overlap && static_cast<int32>(layer_events_.size()) < L) layer_events_.resize(L, NULL);
   bool side_used = false;
+  // to be called before the back-propagation of layer i is queued
+  auto err_ready = [&](int32 i) {
+    if (!overlap || !nnet_[i]->IsUpdatable()) return;
+    if (nnet_[i]->GetType() != Component::kBiasedLinearity) return;
+    BiasedLinearity *bl = static_cast<BiasedLinearity *>(nnet_[i]);
+    bl->SetDoubleBuffer(dp_ranks_ == 1);
+    if (bl->UpdateKeepsOldWeights() || dp_ranks_ > 1) dev.Order(dev.MainStream(), dev.SideStream(), &layer_events_[i]);
+  };
   auto update = [&](int32 i, const CuMatrix<BaseFloat> &input, const CuMatrix<BaseFloat> &err) {
     if (!overlap || !nnet_[i]->IsUpdatable()) {
       UpdateLayer(i, input, err);
       return;
     }
+    UpdatableComponent *uc = dynamic_cast<UpdatableComponent *>(nnet_[i]);
+    if (!(uc->GetLearnRate() > 0.0)) return;
+    side_used = true;
+    BiasedLinearity *bl = (nnet_[i]->GetType() == Component::kBiasedLinearity) ? static_cast<BiasedLinearity *>(nnet_[i]) : NULL;
+    if (bl != NULL && dp_ranks_ > 1) {
+      // gradient and its all-reduce beside the backward pass; the step itself rewrites the
+      // weights in place, so it waits for this layer's back-propagation
+      CuStreamScope scope(dev.SideStream());
+      DataParallelGradient(i, bl, input, err);
+      dev.Order(dev.MainStream(), dev.SideStream(), &layer_events_[i]);
+      bl->ApplyGradient(dp_grad_, input.NumRows() * dp_ranks_);
+      return;
+    }
+    if (bl != NULL && bl->UpdateKeepsOldWeights()) {
+      // both halves on the side stream: the main stream's chain (back-propagation GEMM, its
+      // slab sum) stays as short as possible, since the next layer's pair waits for it
+      CuStreamScope scope(dev.SideStream());
+      bl->UpdateWeights(input, err);
+      bl->UpdateBias(err);
+      return;
+    }
     dev.Order(dev.MainStream(), dev.SideStream(), &layer_events_[i]);
     CuStreamScope scope(dev.SideStream());
-    UpdateLayer(i, input, err);
-    side_used = true;
+    uc->Update(input, err);
   };
 
   const CuMatrix<BaseFloat> *err = &in_err;  // error w.r.t. the output of layer i
@@ -141,12 +179,14 @@ void Nnet::Backpropagate(const CuMatrix<BaseFloat> &in_err, CuMatrix<BaseFloat> 
       // this layer and the sigmoid below it in one step; y = propagate_buf_[i] is that sigmoid's output
       BiasedLinearity *bl = static_cast<BiasedLinearity *>(comp);
       CuMatrix<BaseFloat> *below2 = (i - 1 > 0) ? &backpropagate_buf_[i - 2] : out_err;
+      err_ready(i);
       if (below2 != NULL) bl->BackpropagateFused(*err, propagate_buf_[i], below2);
       update(i, propagate_buf_[i], *err);
       err = below2;
       i -= 2;
       continue;
     }
+    err_ready(i);
     if (below != NULL) comp->Backpropagate(*err, below);
     update(i, propagate_buf_[i], *err);
     err = below;

@@ -75,6 +75,8 @@ class Nnet {
  private:
   typedef std::vector<Component *> NnetType;
   void UpdateLayer(int32 i, const CuMatrix<BaseFloat> &input, const CuMatrix<BaseFloat> &err);
+  void DataParallelGradient(int32 i, class BiasedLinearity *bl, const CuMatrix<BaseFloat> &input,
+                            const CuMatrix<BaseFloat> &err);
 
   NnetType nnet_;
   std::vector<CuMatrix<BaseFloat> > propagate_buf_;
