@@ -521,8 +521,12 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(GemmParams p, const fl
 
 struct TileCfg {
   int bm, bn;
+  int lds_bytes;   // LDS per workgroup (K-major operands, the larger image)
+  int vgprs;       // registers per lane, rounded
+  double fixed;    // prologue + last tile + epilogue of a workgroup, cycles (measured with in-kernel stamps)
 };
-const TileCfg kCfgs[] = {{64, 64}, {128, 64}, {64, 128}, {128, 128}};
+const TileCfg kCfgs[] = {{64, 64, 36864, 104, 4400.0}, {128, 64, 55296, 176, 5500.0}, {64, 128, 55296, 176, 5500.0},
+                         {128, 128, 73728, 208, 8300.0}};
 constexpr int kBK = 32;
 
 struct Plan {
@@ -531,13 +535,20 @@ struct Plan {
   int k_per_split;
 };
 
-// Rough cycle model used to pick the tile and the split: MFMA time of the busiest CU, the
-// L2->LDS staging rate a CU sustains, a fixed prologue/epilogue cost per block, and the HBM
-// round trip of the partial slabs plus the extra launch when K is split.
+// Picks the tile and the K split.  Measured on the hot-path shapes (M = 256 rows; 440..9000
+// columns and depth), the 64x64 tile is within 2 % of the best tile everywhere and clearly best
+// for the weight-update GEMMs, so the larger tiles are only used when forced (experiments).
+// What is left is the split, chosen with a small cycle model of the 64x64 kernel: a workgroup
+// pulls its operand tiles through L2 at the ~12.5 B/clk a CU sustains for this access pattern
+// (that, not the MFMA rate, bounds a 64x64 tile), the busiest CU runs ceil(workgroups / CUs) of
+// them, the fixed part of a workgroup (prologue, last tile, epilogue: ~4400 cycles by in-kernel
+// stamps) is paid once because co-resident workgroups cover each other's, and a split K adds the
+// slab round trip plus the launch of the kernel that sums the slabs.  The picks were checked
+// against a sweep over every tile / split for the Switchboard- and RM-sized layers.
 int force_bm = -1, force_bn = -1, force_s = -1;
 bool env_read = false;
 
-Plan make_plan(int M, int N, int K, int num_cu, bool allow_split) {
+Plan make_plan(int M, int N, int K, int num_cu, bool allow_split, bool always_slabs) {
   if (!env_read) {
     env_read = true;
     const char *e = getenv("KALDI_HIP_GEMM_FORCE");  // "BM,BN,S" for experiments
@@ -547,10 +558,11 @@ Plan make_plan(int M, int N, int K, int num_cu, bool allow_split) {
   double best_cost = 1e300;
   const int ncfg = (int)(sizeof(kCfgs) / sizeof(kCfgs[0]));
   const int ktiles = (K + kBK - 1) / kBK;
+  const double cyc_per_us = 2050.0;  // clock held under fp32 MFMA load
   for (int c = 0; c < ncfg; ++c) {
-    const int bm = kCfgs[c].bm, bn = kCfgs[c].bn;
-    if (force_bm > 0 && (bm != force_bm || bn != force_bn)) continue;
-    const int tm = (M + bm - 1) / bm, tn = (N + bn - 1) / bn;
+    const TileCfg &t = kCfgs[c];
+    if (force_bm > 0 ? (t.bm != force_bm || t.bn != force_bn) : (c != 0)) continue;
+    const int tm = (M + t.bm - 1) / t.bm, tn = (N + t.bn - 1) / t.bn;
     for (int s = 1; s <= 16; s *= 2) {
       if (s > 1 && !allow_split) break;
       if (force_s > 0 && s != force_s) continue;
@@ -559,13 +571,15 @@ Plan make_plan(int M, int N, int K, int num_cu, bool allow_split) {
       const int s_eff = (ktiles + kt_per - 1) / kt_per;
       if (s_eff != s) continue;
       const double blocks = (double)tm * tn * s;
-      const double rounds = ceil(blocks / num_cu);
       const double kper = (double)kt_per * kBK;
-      const double mfma_cyc = (double)bm * bn * kper * 2.0 / 256.0;
-      const double load_cyc = (double)(bm + bn) * kper * 4.0 / 20.0;
-      double blk = (mfma_cyc > load_cyc ? mfma_cyc : load_cyc) + 3000.0;
-      double cost = rounds * blk;
-      if (s > 1) cost += 2.0 * s * (double)M * N * 4.0 / 4.0e12 * 2.4e9 + 5000.0;
+      const double mfma = (double)t.bm * t.bn * kper * 2.0 / 256.0 * 1.08;
+      const double mem = (double)(t.bm + t.bn) * kper * 4.0 / 12.5;
+      const double per_block = mfma > mem ? mfma : mem;
+      const double n = ceil(blocks / num_cu);
+      // with two or more workgroups on every CU one's stalls are filled by another's MFMAs
+      const double share = blocks >= 2.0 * num_cu ? 0.9 : 1.0;
+      double cost = (n * per_block * share + t.fixed) / cyc_per_us;
+      if (s > 1 || always_slabs) cost += (s + 1.0) * (double)M * N * 4.0 / 3.5e6 + 2.5;
       if (cost < best_cost) {
         best_cost = cost;
         best.cfg = c;
@@ -666,7 +680,8 @@ template <int EPI>
 int run_gemm(khStream_t s, bool a_kmajor, bool b_kmajor, GemmParams p, bool allow_split, bool softmax = false) {
   hipStream_t st = kh::pick(s);
   const bool vec = kh::aligned16(p.A) && kh::aligned16(p.B) && (p.lda % 4 == 0) && (p.ldb % 4 == 0);
-  Plan plan = make_plan(p.M, p.N, p.K, kh::ctx().num_cu > 0 ? kh::ctx().num_cu : 256, allow_split || softmax);
+  Plan plan = make_plan(p.M, p.N, p.K, kh::ctx().num_cu > 0 ? kh::ctx().num_cu : 256, allow_split || softmax,
+                        softmax);
   const int bm = kCfgs[plan.cfg].bm, bn = kCfgs[plan.cfg].bn;
   p.tiles_m = (p.M + bm - 1) / bm;
   p.tiles_n = (p.N + bn - 1) / bn;
