@@ -222,10 +222,12 @@ int hipF_gemm(khStream_t s, int transA, int transB, int32_t M, int32_t N, int32_
 
 /* Measurement aid: with timing enabled every GEMM main-kernel launch (hipF_gemm and the fused
  * affine / rbm entry points) is bracketed by two HIP events on its stream.  hipK_gemm_timing_read
- * blocks until they have completed, returns the summed kernel time, the number of launches and
- * their algorithmic FLOPs (2*M*N*K each), and clears the record.  Off by default. */
+ * blocks until they have completed, returns the summed kernel time, the time during which at
+ * least one of them was running (launches queued on two streams overlap, so this is less than the
+ * sum), the number of launches and their algorithmic FLOPs (2*M*N*K each), and clears the record.
+ * Off by default. */
 int hipK_gemm_timing(int enable);
-int hipK_gemm_timing_read(double *total_ms, long long *launches, double *flops);
+int hipK_gemm_timing_read(double *total_ms, double *busy_ms, long long *launches, double *flops);
 
 /* Tuning aid: pin the tile (bm x bn) and the split-K factor of every following GEMM instead of
  * letting the library choose; zeros restore the automatic choice.  Also settable at start-up with
@@ -328,6 +330,11 @@ int hipF_rbm_update(khStream_t s, int32_t N, int32_t H, int32_t V, const float *
 #define KH_COMM_ID_BYTES 128
 int hipK_comm_get_unique_id(unsigned char id[KH_COMM_ID_BYTES]);
 int hipK_comm_init(const unsigned char id[KH_COMM_ID_BYTES], int rank, int nranks);
+/* Single-process stand-in for `nranks` replicas that all hold exactly this process's data: a sum
+ * all-reduce multiplies by nranks, min / max and the barrier are local.  Lets the data-parallel
+ * code path (gradient -> all-reduce -> step) be validated on one GPU: training on a bunch X with
+ * a loopback of n equals single-process training on n stacked copies of X. */
+int hipK_comm_init_loopback(int nranks);
 int hipK_comm_destroy(void);
 int hipK_comm_rank(int *rank, int *nranks);
 /* in-place sum all-reduce of count floats on stream s (ordered with the kernels on s) */

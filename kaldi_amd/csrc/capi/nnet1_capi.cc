@@ -1,4 +1,5 @@
 #include "capi/nnet1_capi.h"
+#include "nnetbin/dist-utils.h"
 
 #include <string>
 
@@ -240,6 +241,22 @@ int nnet1_synchronize(void) {
   CuDevice::Instantiate().Synchronize();
   return 0;
   CAPI_CATCH(-1)
+}
+
+
+int nnet1_shard_assign(int num_ranks, int n, const long long *num_frames, int *rank_out) {
+  if (num_ranks < 1 || n < 0 || (n > 0 && (!num_frames || !rank_out))) return -1;
+  kaldi::ShardAssigner shard(num_ranks);
+  for (int i = 0; i < n; ++i) rank_out[i] = shard.Assign(num_frames[i]);
+  return 0;
+}
+
+int nnet1_substitute_job(const char *spec, int rank, char *out, int out_len) {
+  if (!spec || !out || out_len <= 0 || rank < 0) return -1;
+  const std::string r = kaldi::SubstituteJob(spec, rank);
+  if (static_cast<int>(r.size()) + 1 > out_len) return -1;
+  memcpy(out, r.c_str(), r.size() + 1);
+  return 0;
 }
 
 }  // extern "C"

@@ -42,6 +42,11 @@ int rbm1_dims(void *h, int *vis, int *hid);
 int nnet1_synchronize(void);
 /* the host random stream (kaldi::Rand after kaldi::SRand(seed)): n draws, for tests */
 int nnet1_rand_stream(unsigned int seed, int n, int *out);
+/* Host-only helpers of the multi-GPU tools (no GPU needed): the utterance -> rank rule of the
+ * sharded nnet-forward (each utterance to the rank with the fewest frames so far) and the JOB
+ * substitution in output specifiers. */
+int nnet1_shard_assign(int num_ranks, int n, const long long *num_frames, int *rank_out);
+int nnet1_substitute_job(const char *spec, int rank, char *out, int out_len);
 #ifdef __cplusplus
 }
 #endif

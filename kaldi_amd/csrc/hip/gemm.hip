@@ -20,7 +20,9 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <type_traits>
+#include <utility>
 #include <vector>
 
 #include "common.h"
@@ -884,18 +886,40 @@ KH_EXPORT int hipK_gemm_timing(int enable) {
   return KH_OK;
 }
 
-KH_EXPORT int hipK_gemm_timing_read(double *total_ms, long long *launches, double *flops) {
+KH_EXPORT int hipK_gemm_timing_read(double *total_ms, double *busy_ms, long long *launches, double *flops) {
   GemmTiming &t = timing();
   double ms = 0.0;
+  std::vector<std::pair<double, double> > iv;  // [start, end) of every launch, ms since the first one's start
   for (size_t i = 0; i < t.spans.size(); ++i) {
     KH_HIP(hipEventSynchronize(t.spans[i].second));
-    float one = 0.f;
+    float one = 0.f, off = 0.f;
     KH_HIP(hipEventElapsedTime(&one, t.spans[i].first, t.spans[i].second));
+    if (i > 0) {
+      KH_HIP(hipEventSynchronize(t.spans[i].first));
+      KH_HIP(hipEventElapsedTime(&off, t.spans[0].first, t.spans[i].first));
+    }
     ms += one;
+    iv.push_back(std::make_pair((double)off, (double)off + one));
+  }
+  // length of the union of the intervals
+  std::sort(iv.begin(), iv.end());
+  double busy = 0.0, cur_a = 0.0, cur_b = -1.0;
+  for (size_t i = 0; i < iv.size(); ++i) {
+    if (cur_b < cur_a || iv[i].first > cur_b) {
+      if (cur_b > cur_a) busy += cur_b - cur_a;
+      cur_a = iv[i].first;
+      cur_b = iv[i].second;
+    } else if (iv[i].second > cur_b) {
+      cur_b = iv[i].second;
+    }
+  }
+  if (cur_b > cur_a) busy += cur_b - cur_a;
+  for (size_t i = 0; i < t.spans.size(); ++i) {
     t.pool.push_back(t.spans[i].first);
     t.pool.push_back(t.spans[i].second);
   }
   if (total_ms) *total_ms = ms;
+  if (busy_ms) *busy_ms = busy;
   if (launches) *launches = (long long)t.spans.size();
   if (flops) *flops = t.flops;
   t.spans.clear();

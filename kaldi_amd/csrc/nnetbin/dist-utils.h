@@ -41,10 +41,11 @@ struct DistOptions {
   }
 };
 
-/// selects the GPU and, with more than one rank, builds the RCCL communicator
-inline void DistInit(const DistOptions &o) {
+/// selects the GPU and, with more than one rank and need_comm, builds the RCCL communicator
+/// (a tool whose ranks never exchange data, like nnet-forward, passes need_comm = false)
+inline void DistInit(const DistOptions &o, bool need_comm = true) {
   CuDevice::Instantiate().SelectGpuId(o.gpu_id);
-  if (o.num_ranks == 1) return;
+  if (o.num_ranks == 1 || !need_comm) return;
   unsigned char id[KH_COMM_ID_BYTES];
   const std::string tmp = o.comm_id_file + ".tmp";
   if (o.rank == 0) {
@@ -71,8 +72,8 @@ inline void DistInit(const DistOptions &o) {
   if (o.rank == 0) remove(o.comm_id_file.c_str());  // every rank has joined
 }
 
-inline void DistFinalize(const DistOptions &o) {
-  if (o.num_ranks > 1) CU_SAFE_CALL(hipK_comm_destroy());
+inline void DistFinalize(const DistOptions &o, bool need_comm = true) {
+  if (o.num_ranks > 1 && need_comm) CU_SAFE_CALL(hipK_comm_destroy());
 }
 
 /// all-reduce of one host integer (op 0 sum, 1 min, 2 max); blocking

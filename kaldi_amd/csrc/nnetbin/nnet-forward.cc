@@ -59,7 +59,7 @@ int main(int argc, char *argv[]) {
 
     dist.Resolve();
     if (silent) CuDevice::Instantiate().Verbose(false);
-    DistInit(dist);
+    DistInit(dist, /*need_comm=*/false);  // shards are independent: no collective on this path
     if (dist.num_ranks > 1) feature_wspecifier = SubstituteJob(feature_wspecifier, dist.rank);
 
     Nnet nnet_transf;
@@ -122,7 +122,7 @@ int main(int argc, char *argv[]) {
     if (!silent) KALDI_LOG << "MLP FEEDFORWARD FINISHED " << tim.Elapsed() << "s, fps" << tot_t / tim.Elapsed();
     if (!silent) KALDI_LOG << "Done " << num_done << " files";
     if (!silent) CuDevice::Instantiate().PrintProfile();
-    DistFinalize(dist);
+    DistFinalize(dist, /*need_comm=*/false);
     return ((num_done > 0) ? 0 : 1);
   } catch (const std::exception &e) {
     std::cerr << e.what();

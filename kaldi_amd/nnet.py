@@ -38,6 +38,8 @@ _SIGS = {
     "rbm1_write": (I, [P, ctypes.c_char_p, I]),
     "rbm1_dims": (I, [P, P, P]),
     "nnet1_synchronize": (I, []),
+    "nnet1_shard_assign": (I, [I, I, P, P]),
+    "nnet1_substitute_job": (I, [ctypes.c_char_p, I, ctypes.c_char_p, I]),
 }
 for _n, (_r, _a) in _SIGS.items():
     _f = getattr(lib, _n)
@@ -143,6 +145,20 @@ class RbmTrainer:
             self.close()
         except Exception:
             pass
+
+
+def shard_assign(num_ranks, num_frames):
+    """Rank of every utterance under the sharded nnet-forward's rule (host only, no GPU)."""
+    nf = np.ascontiguousarray(num_frames, dtype=np.int64)
+    out = np.zeros(nf.size, np.int32)
+    _check(lib.nnet1_shard_assign(num_ranks, nf.size, nf.ctypes.data, out.ctypes.data))
+    return out
+
+
+def substitute_job(spec, rank):
+    buf = ctypes.create_string_buffer(len(spec) + 32)
+    _check(lib.nnet1_substitute_job(spec.encode(), rank, buf, len(buf)))
+    return buf.value.decode()
 
 
 def synchronize():

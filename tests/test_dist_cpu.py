@@ -1,0 +1,154 @@
+"""Multi-rank logic on the CPU (gloo, world size 2): what the N>1 paths rely on, checked without a GPU.
+
+  * data-parallel training: every rank computes the raw gradient sums of its own bunch, the sums are
+    all-reduced, every rank applies the same step with the total frame count.  With the oracle's
+    arithmetic on both sides this must equal one process training on the concatenated bunch (the
+    property the RCCL path of Nnet::SetDataParallel is built on; the GPU form of the same check is
+    tests/test_gpu_dist.py).
+  * sharded nnet-forward: every rank evaluates the utterance -> rank rule on its own while streaming
+    the same table; the ranks must agree, cover every utterance exactly once and balance frames.
+  * per-cache bunch-count agreement (min over ranks), as used by the data-parallel training tool.
+"""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import nnet1_oracle as O  # noqa: E402
+
+f32 = np.float32
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _make_net(rs, dims):
+    layers = []
+    for i in range(len(dims) - 1):
+        layers.append(O.BiasedLinearity((0.3 * rs.standard_normal((dims[i + 1], dims[i]))).astype(f32),
+                                        (0.1 * rs.standard_normal(dims[i + 1])).astype(f32)))
+        layers.append(O.Sigmoid(dims[i + 1]) if i + 2 < len(dims) else O.Softmax(dims[i + 1]))
+    return O.Nnet(layers)
+
+
+def _dp_step(net, x, tgt, world, allreduce, lr, mom, avg):
+    """One synchronous data-parallel step in the oracle's arithmetic (gradient sums -> all-reduce ->
+    the update of nnet-biasedlinearity.h:71-102 with the global frame count)."""
+    post = net.propagate(x)
+    err, _ = O.diff_xent(tgt, post)
+    buf = net.propagate_buf
+    L = len(net.layers)
+    cur = err
+    for i in range(L - 1, -1, -1):
+        l = net.layers[i]
+        below = l.backpropagate(cur, buf[i], buf[i + 1]) if i > 0 else None
+        if l.updatable:
+            gW = O.gemm(1.0, cur, True, buf[i], False, 0.0, None)
+            gb = O.add_row_sum_mat(1.0, cur, 0.0, np.zeros(l.dim_out, f32))
+            flat = np.concatenate([gW.ravel(), gb]).astype(f32)
+            flat = allreduce(flat)
+            gW, gb = flat[:gW.size].reshape(gW.shape), flat[gW.size:]
+            n_total = x.shape[0] * world
+            g = f32(1.0 / n_total) if avg else f32(1.0)
+            l.W_corr = (g * gW + f32(mom) * l.W_corr).astype(f32)
+            l.b_corr = (g * gb + f32(mom) * l.b_corr).astype(f32)
+            l.W = (f32(-lr) * l.W_corr + l.W).astype(f32)
+            l.b = (f32(-lr) * l.b_corr + l.b).astype(f32)
+        cur = below
+    return post
+
+
+def _worker(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    try:
+        dims = [20, 24, 16, 9]
+        lr, mom, avg, nsteps, nb = 0.05, 0.5, True, 3, 32
+        rs = np.random.RandomState(7)
+        net = _make_net(rs, dims)
+        X = rs.standard_normal((nsteps, world * nb, dims[0])).astype(f32)
+        T = rs.randint(0, dims[-1], (nsteps, world * nb)).astype(np.int32)
+
+        def allreduce(v):
+            t = torch.from_numpy(v.copy())
+            dist.all_reduce(t)
+            return t.numpy()
+
+        for s in range(nsteps):
+            xs, ts = X[s, rank * nb:(rank + 1) * nb], T[s, rank * nb:(rank + 1) * nb]
+            _dp_step(net, xs, ts, world, allreduce, lr, mom, avg)
+        params = np.concatenate([np.concatenate([l.W.ravel(), l.b]) for l in net.layers if l.updatable])
+
+        # sharded forward: every rank evaluates the rule itself from the same table
+        import kaldi_amd.nnet as nn
+        lens = np.random.RandomState(3).randint(1, 900, 257)
+        mine = nn.shard_assign(world, lens)
+        gathered = [torch.zeros(lens.size, dtype=torch.int32) for _ in range(world)]
+        dist.all_gather(gathered, torch.from_numpy(mine.copy()))
+        agree = all(bool((g.numpy() == mine).all()) for g in gathered)
+        my_frames = int(lens[mine == rank].sum())
+
+        # bunch-count agreement: every rank stops after the smallest count
+        counts = torch.tensor([17 + 5 * rank], dtype=torch.int64)
+        dist.all_reduce(counts, op=dist.ReduceOp.MIN)
+        q.put((rank, params, agree, my_frames, int(lens.sum()), int(counts.item())))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_data_parallel_step_equals_single_process_and_shards_agree():
+    import torch.multiprocessing as mp
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+
+    # single process on the concatenated bunches, the oracle's own update
+    dims = [20, 24, 16, 9]
+    lr, mom, nsteps, nb = 0.05, 0.5, 3, 32
+    rs = np.random.RandomState(7)
+    net = _make_net(rs, dims)
+    net.set_train_opts(lr, mom, average_grad=True)
+    X = rs.standard_normal((nsteps, world * nb, dims[0])).astype(f32)
+    T = rs.randint(0, dims[-1], (nsteps, world * nb)).astype(np.int32)
+    for s in range(nsteps):
+        post = net.propagate(X[s])
+        net.backpropagate(O.diff_xent(T[s], post)[0])
+    ref = np.concatenate([np.concatenate([l.W.ravel(), l.b]) for l in net.layers if l.updatable])
+
+    np.testing.assert_array_equal(res[0][1], res[1][1])                      # replicas stay identical
+    np.testing.assert_allclose(res[0][1], ref, rtol=2e-5, atol=2e-6)         # and match one big bunch
+    assert res[0][2] and res[1][2]                                            # same shard map on every rank
+    total = res[0][4]
+    assert res[0][3] + res[1][3] == total                                     # every frame exactly once
+    assert abs(res[0][3] - res[1][3]) <= 900                                  # balanced to one utterance
+    assert res[0][5] == res[1][5] == 17                                       # min over ranks
+
+
+def test_shard_rule_and_job_substitution():
+    import kaldi_amd.nnet as nn
+    lens = [10, 10, 5, 1, 30, 2]
+    assert nn.shard_assign(1, lens).tolist() == [0] * 6
+    # fewest frames so far, lowest rank on ties
+    assert nn.shard_assign(2, lens).tolist() == [0, 1, 0, 1, 1, 0]
+    assert nn.shard_assign(3, []).tolist() == []
+    assert nn.substitute_job("ark:out.JOB.ark", 2) == "ark:out.3.ark"
+    assert nn.substitute_job("ark,scp:a.JOB.ark,a.JOB.scp", 0) == "ark,scp:a.1.ark,a.1.scp"
+    assert nn.substitute_job("ark:plain.ark", 5) == "ark:plain.ark"

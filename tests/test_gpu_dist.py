@@ -1,0 +1,100 @@
+"""GPU checks of the multi-GPU code paths that one GPU can exercise.
+
+  * data-parallel training path (gradient GEMM -> all-reduce -> shared step, Nnet::SetDataParallel)
+    with the loopback communicator: n replicas that hold the same bunch X must train exactly like one
+    process on n stacked copies of X with gradient averaging over n*|X| frames.
+  * utterance-sharded nnet-forward: two rank processes (no collective on this path) share the GPU;
+    the union of their outputs equals the single-process output bit for bit.
+"""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import nnet1_oracle as O
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+f32 = np.float32
+
+
+@pytest.fixture(scope="module")
+def nn(hip):
+    import kaldi_amd.nnet as n
+    return n
+
+
+def _model_bytes(rs, dims):
+    layers = []
+    for i in range(len(dims) - 1):
+        layers.append(O.BiasedLinearity((0.2 * rs.standard_normal((dims[i + 1], dims[i]))).astype(f32),
+                                        (0.1 * rs.standard_normal(dims[i + 1])).astype(f32)))
+        layers.append(O.Sigmoid(dims[i + 1]) if i + 2 < len(dims) else O.Softmax(dims[i + 1]))
+    return O.write_nnet(layers, True), layers
+
+
+@pytest.mark.parametrize("mom,avg", [(0.0, True), (0.5, True), (0.0, False)])
+def test_data_parallel_path_equals_stacked_bunch(hip, nn, tmp_path, mom, avg):
+    rs = np.random.RandomState(11)
+    dims = [40, 96, 64, 33]
+    data, _ = _model_bytes(rs, dims)
+    model = tmp_path / "m.nnet"
+    model.write_bytes(data)
+    N, R, steps, lr = 64, 2, 3, 0.05
+    X = rs.standard_normal((steps, N, dims[0])).astype(f32)
+    T = rs.randint(0, dims[-1], (steps, N)).astype(np.int32)
+
+    hip.call("hipK_comm_init_loopback", R)
+    try:
+        dp = nn.Trainer(str(model))
+        dp.set_train_opts(lr, mom, 0.0, 0.0, 0.0, avg, True)
+        dp.set_data_parallel(R)
+        for s in range(steps):
+            x = hip.DevMatrix.from_numpy(X[s])
+            t = hip.DevMatrix.from_numpy(T[s], pitched=False)
+            dp.train_bunch(x.ptr, x.stride, N, dims[0], t.ptr)
+        dp_params = [dp.layer_params(i, dims[i // 2 + 1], dims[i // 2]) for i in (0, 2, 4)]
+        dp.close()
+    finally:
+        hip.call("hipK_comm_destroy")
+
+    one = nn.Trainer(str(model))
+    one.set_train_opts(lr, mom, 0.0, 0.0, 0.0, avg, True)
+    for s in range(steps):
+        x = hip.DevMatrix.from_numpy(np.concatenate([X[s]] * R))
+        t = hip.DevMatrix.from_numpy(np.concatenate([T[s]] * R), pitched=False)
+        one.train_bunch(x.ptr, x.stride, N * R, dims[0], t.ptr)
+    for i, (W, b) in zip((0, 2, 4), dp_params):
+        W1, b1 = one.layer_params(i, dims[i // 2 + 1], dims[i // 2])
+        np.testing.assert_allclose(W, W1, rtol=2e-5, atol=2e-6)
+        np.testing.assert_allclose(b, b1, rtol=2e-5, atol=2e-6)
+    one.close()
+
+
+def test_forward_sharded_over_two_ranks_equals_single(hip, nn, tmp_path):
+    rs = np.random.RandomState(5)
+    dims = [30, 64, 21]
+    data, _ = _model_bytes(rs, dims)
+    (tmp_path / "m.nnet").write_bytes(data)
+    lens = [7, 130, 33, 1, 64, 250, 18, 90, 5]
+    utts = [("u%02d" % i, rs.standard_normal((n, dims[0])).astype(f32)) for i, n in enumerate(lens)]
+    (tmp_path / "f.ark").write_bytes(O.write_matrix_ark(utts))
+    exe = os.path.join(nn.BIN_DIR, "nnet-forward")
+    base = [exe, "--silent=true", str(tmp_path / "m.nnet"), "ark:" + str(tmp_path / "f.ark")]
+    r = subprocess.run(base + ["ark:" + str(tmp_path / "single.ark")], stderr=subprocess.PIPE, timeout=110)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    procs = [subprocess.Popen([exe, "--silent=true", "--num-ranks=2", "--rank=%d" % k, "--gpu-id=0",
+                               str(tmp_path / "m.nnet"), "ark:" + str(tmp_path / "f.ark"),
+                               "ark:" + str(tmp_path / "shard.JOB.ark")], stderr=subprocess.PIPE) for k in range(2)]
+    for p in procs:
+        _, err = p.communicate(timeout=110)
+        assert p.returncode == 0, err.decode()[-2000:]
+    single = dict(O.read_matrix_ark((tmp_path / "single.ark").read_bytes()))
+    shards = [dict(O.read_matrix_ark((tmp_path / ("shard.%d.ark" % (k + 1))).read_bytes())) for k in range(2)]
+    assert not set(shards[0]) & set(shards[1])
+    assert set(shards[0]) | set(shards[1]) == set(single)
+    want = nn.shard_assign(2, lens)
+    for i, (k, _) in enumerate(utts):
+        assert k in shards[want[i]]                                    # the documented rule
+        np.testing.assert_array_equal(shards[want[i]][k], single[k])   # same kernels, same rows: bit for bit
