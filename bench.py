@@ -216,6 +216,12 @@ def main():
         # counted once); per_launch = the same FLOPs / summed launch durations
         achieved = fl.value / (busy.value * 1e-3) / 1e12 if busy.value > 0 else 0.0
         per_launch = fl.value / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0
+        # HBM-side bytes per GEMM launch come from rocprofv3 PMC passes of this same command (their
+        # summary is committed; a PMC pass cannot run inside the timed process)
+        traffic = None
+        tf = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "gemm_traffic.json")
+        if args.workload == "swbd" and os.path.exists(tf):
+            traffic = json.load(open(tf)).get("gemm_hbm_bytes_per_launch")
         out = {
             "metric": "DNN train frames/sec (fwd+bwd+update), %s" % args.workload,
             "value": round(value, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -226,7 +232,7 @@ def main():
                        "pct_fp32_mfma_peak_end_to_end": round(100.0 * value * fpf / world / (F32_MFMA_PEAK_TFLOPS * 1e12), 2)},
             "roofline": {"bound": "mfma", "kernel": "gemm_kernel (fp32 v_mfma_f32_32x32x2_f32, all layouts)",
                          "achieved": round(achieved, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                         "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
                          "launches_per_step": launches.value / roof_steps,
                          "gemm_busy_ms_per_step": round(busy.value / roof_steps, 4),
                          "gemm_launch_ms_sum_per_step": round(ms.value / roof_steps, 4),
