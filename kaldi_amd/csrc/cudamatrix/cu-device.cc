@@ -22,6 +22,7 @@ void CuDevice::SelectGpuId(int32 gpu_id) {
   CU_SAFE_CALL(hipK_default_stream(&main_stream_));
   stream_ = main_stream_;
   side_stream_ = NULL;
+  aux_stream_ = NULL;
   initialised_ = true;
   if (verbose_) {
     char arch[64];

@@ -55,6 +55,13 @@ class CuDevice {
     if (side_stream_ == NULL) CU_SAFE_CALL(hipK_stream_create(&side_stream_));
     return side_stream_;
   }
+  /// A third stream for small independent kernels (bias updates) that must not sit in the way of
+  /// either chain of GEMMs; same rules as the side stream.
+  khStream_t AuxStream() {
+    EnsureInit();
+    if (aux_stream_ == NULL) CU_SAFE_CALL(hipK_stream_create(&aux_stream_));
+    return aux_stream_;
+  }
   /// `waiter` continues only after everything queued on `done` so far has finished (no host wait).
   void Order(khStream_t done, khStream_t waiter, khEvent_t *ev) {
     if (*ev == NULL) CU_SAFE_CALL(hipK_event_create(ev));
@@ -73,12 +80,12 @@ class CuDevice {
   friend class CuStreamScope;
   CuDevice()
       : initialised_(false), requested_gpu_id_(-1), active_gpu_id_(-1), verbose_(true), profiling_(false),
-        stream_(NULL), main_stream_(NULL), side_stream_(NULL) {}
+        stream_(NULL), main_stream_(NULL), side_stream_(NULL), aux_stream_(NULL) {}
   ~CuDevice() {}
   bool initialised_;
   int32 requested_gpu_id_, active_gpu_id_;
   bool verbose_, profiling_;
-  khStream_t stream_, main_stream_, side_stream_;
+  khStream_t stream_, main_stream_, side_stream_, aux_stream_;
   std::map<std::string, double> profile_map_;
   KALDI_DISALLOW_COPY_AND_ASSIGN(CuDevice);
 };

@@ -93,6 +93,84 @@ __global__ __launch_bounds__(kSoftmaxThreads) void softmax_kernel(float *y, int 
   for (int c = t; c < cols; c += kSoftmaxThreads) py[c] = (STAGED ? row[c] : py[c]) * inv;
 }
 
+// Register-resident form: every thread owns NV float4 of the row (slabs and bias summed in the same
+// order as above), all loads in flight together, one read and one write of the row.  Needs 16-byte
+// aligned rows / slabs / bias and cols <= 4 * kSoftmaxThreads * NV.
+template <int NV>
+__global__ __launch_bounds__(kSoftmaxThreads) void softmax_vec_kernel(float *y, int ldy, const float *x, int ldx,
+                                                                      int nslab, size_t slab_stride,
+                                                                      const float *bias, int cols) {
+  __shared__ float red[16];
+  const int r = blockIdx.x;
+  const float *px = x + (size_t)r * ldx;
+  float *py = y + (size_t)r * ldy;
+  const int t = threadIdx.x;
+  const int cols4 = (cols + 3) & ~3;  // whole float4s inside the padded row
+  float4 v[NV];
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const int c = (t + k * kSoftmaxThreads) * 4;
+    v[k] = (c < cols4) ? *reinterpret_cast<const float4 *>(px + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  for (int sl = 1; sl < nslab; ++sl) {
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const int c = (t + k * kSoftmaxThreads) * 4;
+      if (c < cols4) {
+        const float4 a = *reinterpret_cast<const float4 *>(px + (size_t)sl * slab_stride + c);
+        v[k].x += a.x; v[k].y += a.y; v[k].z += a.z; v[k].w += a.w;
+      }
+    }
+  }
+  if (bias) {
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const int c = (t + k * kSoftmaxThreads) * 4;
+      if (c + 3 < cols) {
+        const float4 a = *reinterpret_cast<const float4 *>(bias + c);
+        v[k].x += a.x; v[k].y += a.y; v[k].z += a.z; v[k].w += a.w;
+      } else if (c < cols) {
+        v[k].x += bias[c];
+        if (c + 1 < cols) v[k].y += bias[c + 1];
+        if (c + 2 < cols) v[k].z += bias[c + 2];
+      }
+    }
+  }
+  float mx = -INFINITY;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const int c = (t + k * kSoftmaxThreads) * 4;
+    if (c < cols) mx = fmaxf(mx, v[k].x);
+    if (c + 1 < cols) mx = fmaxf(mx, v[k].y);
+    if (c + 2 < cols) mx = fmaxf(mx, v[k].z);
+    if (c + 3 < cols) mx = fmaxf(mx, v[k].w);
+  }
+  mx = kh::block_max(mx, red);
+  float sum = 0.f;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const int c = (t + k * kSoftmaxThreads) * 4;
+    v[k].x = (c < cols) ? expf(v[k].x - mx) : 0.f;
+    v[k].y = (c + 1 < cols) ? expf(v[k].y - mx) : 0.f;
+    v[k].z = (c + 2 < cols) ? expf(v[k].z - mx) : 0.f;
+    v[k].w = (c + 3 < cols) ? expf(v[k].w - mx) : 0.f;
+    sum += (v[k].x + v[k].y) + (v[k].z + v[k].w);
+  }
+  sum = kh::block_sum(sum, red);
+  const float inv = 1.0f / sum;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const int c = (t + k * kSoftmaxThreads) * 4;
+    if (c + 3 < cols) {
+      *reinterpret_cast<float4 *>(py + c) = make_float4(v[k].x * inv, v[k].y * inv, v[k].z * inv, v[k].w * inv);
+    } else if (c < cols) {
+      py[c] = v[k].x * inv;
+      if (c + 1 < cols) py[c + 1] = v[k].y * inv;
+      if (c + 2 < cols) py[c + 2] = v[k].z * inv;
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void softmax_part_kernel(const float *X, const int32_t *ids, float *Y,
                                                            MatrixDim d) {
   const int c = blockIdx.x * 256 + threadIdx.x;
@@ -208,6 +286,86 @@ __global__ __launch_bounds__(256) void xent_rows_kernel(const float *post, const
     log_post[r] = logf(pt < 1e-20f ? 1e-20f : pt);
   }
 }
+// pass 1, fast form: the row is read once with 16-byte loads into registers (NV float4 per thread,
+// all loads in flight together), then argmax and diff come out of the registers.  Needs 16-byte
+// aligned rows, diff not aliasing post and cols <= 1024 * NV.
+template <int NV>
+__global__ __launch_bounds__(256) void xent_rows_vec_kernel(const float *post, const int32_t *tgt, float *diff,
+                                                            float *log_post, int32_t *max_id, MatrixDim d) {
+  __shared__ float sv[16];
+  __shared__ int32_t si[16];
+  const int r = blockIdx.x;
+  const float *p = post + (size_t)r * d.stride;
+  float *q = diff + (size_t)r * d.stride;
+  const int t = tgt[r];
+  const bool t_ok = (t >= 0 && t < d.cols);
+  float4 v[NV];
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const int c = (threadIdx.x + k * 256) * 4;
+    // whole float4s inside the padded row are readable; columns >= cols are masked below
+    v[k] = (c < d.stride) ? *reinterpret_cast<const float4 *>(p + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  MaxId m;
+  m.v = -1e21f;
+  m.i = -1;
+  float pt = 0.0f;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const int c = (threadIdx.x + k * 256) * 4;
+    float e[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (c + j < d.cols) {
+        if (e[j] > m.v) {
+          m.v = e[j];
+          m.i = c + j;
+        }
+        if (c + j == t) {
+          pt = e[j];
+          e[j] -= 1.0f;
+        }
+      }
+    }
+    if (c + 3 < d.cols) {
+      *reinterpret_cast<float4 *>(q + c) = make_float4(e[0], e[1], e[2], e[3]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (c + j < d.cols) q[c + j] = e[j];
+    }
+  }
+  // per-thread columns ascend with k, so `m` holds the thread's first maximum; combine as in
+  // block_row_argmax (lower index wins ties)
+  m = wave_best(m);
+  // the target's posterior lives in exactly one thread
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) pt += __shfl_xor(pt, o, 64);
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  __shared__ float spt[4];
+  if (lane == 0) {
+    sv[wid] = m.v;
+    si[wid] = m.i;
+    spt[wid] = pt;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    MaxId b;
+    b.v = sv[0];
+    b.i = si[0];
+    float ptot = spt[0];
+    for (int w = 1; w < 4; ++w) {
+      MaxId o;
+      o.v = sv[w];
+      o.i = si[w];
+      b = better(b, o);
+      ptot += spt[w];
+    }
+    max_id[r] = b.i;
+    const float ptv = t_ok ? ptot : 0.0f;
+    log_post[r] = logf(ptv < 1e-20f ? 1e-20f : ptv);
+  }
+}
 // pass 2: one block: counters and loss in a fixed order
 __global__ __launch_bounds__(256) void xent_accum_kernel(const int32_t *tgt, const float *log_post,
                                                          const int32_t *max_id, long long *counters, double *loss,
@@ -270,7 +428,15 @@ __global__ __launch_bounds__(256) void mse_accum_kernel(const float *row_sq, dou
 namespace kh {
 int softmax_slabs_launch(hipStream_t st, float *y, int ldy, const float *x, int ldx, int nslab, size_t slab_stride,
                          const float *bias, int rows, int cols) {
-  if (cols <= kSoftmaxLdsFloats)
+  const bool vec = (ldx % 4 == 0) && (ldy % 4 == 0) && (slab_stride % 4 == 0) && kh::aligned16(x) && kh::aligned16(y) &&
+                   (!bias || kh::aligned16(bias));
+  if (vec && cols <= 4 * kSoftmaxThreads * 2)
+    hipLaunchKernelGGL((softmax_vec_kernel<2>), dim3(rows), dim3(kSoftmaxThreads), 0, st, y, ldy, x, ldx, nslab,
+                       slab_stride, bias, cols);
+  else if (vec && cols <= 4 * kSoftmaxThreads * 5)
+    hipLaunchKernelGGL((softmax_vec_kernel<5>), dim3(rows), dim3(kSoftmaxThreads), 0, st, y, ldy, x, ldx, nslab,
+                       slab_stride, bias, cols);
+  else if (cols <= kSoftmaxLdsFloats)
     hipLaunchKernelGGL((softmax_kernel<true>), dim3(rows), dim3(kSoftmaxThreads), 0, st, y, ldy, x, ldx, nslab,
                        slab_stride, bias, cols);
   else
@@ -358,7 +524,15 @@ KH_EXPORT int hipF_xent_eval(khStream_t s, const float *post, const int32_t *tgt
     if (!mi) mi = (int32_t *)((char *)ws + (size_t)d.rows * 4);
   }
   hipStream_t st = kh::pick(s);
-  hipLaunchKernelGGL(xent_rows_kernel, dim3(d.rows), dim3(256), 0, st, post, tgt, diff, lp, mi, d);
+  const bool vec = (post != diff) && (d.stride % 4 == 0) && kh::aligned16(post) && kh::aligned16(diff);
+  if (vec && d.cols <= 4096)
+    hipLaunchKernelGGL(xent_rows_vec_kernel<4>, dim3(d.rows), dim3(256), 0, st, post, tgt, diff, lp, mi, d);
+  else if (vec && d.cols <= 10240)
+    hipLaunchKernelGGL(xent_rows_vec_kernel<10>, dim3(d.rows), dim3(256), 0, st, post, tgt, diff, lp, mi, d);
+  else if (vec && d.cols <= 16384)
+    hipLaunchKernelGGL(xent_rows_vec_kernel<16>, dim3(d.rows), dim3(256), 0, st, post, tgt, diff, lp, mi, d);
+  else
+    hipLaunchKernelGGL(xent_rows_kernel, dim3(d.rows), dim3(256), 0, st, post, tgt, diff, lp, mi, d);
   hipLaunchKernelGGL(xent_accum_kernel, dim3(1), dim3(256), 0, st, tgt, lp, mi, counters, loss, d.rows);
   return kh::launch_status();
 }

@@ -15,6 +15,7 @@ Nnet::~Nnet() {
   for (size_t i = 0; i < layer_events_.size(); ++i)
     if (layer_events_[i]) hipK_event_destroy(layer_events_[i]);
   if (join_event_) hipK_event_destroy(join_event_);
+  if (aux_join_event_) hipK_event_destroy(aux_join_event_);
 }
 
 MatrixIndexT Nnet::InputDim() const {
@@ -123,7 +124,7 @@ void Nnet::Backpropagate(const CuMatrix<BaseFloat> &in_err, CuMatrix<BaseFloat> 
   CuDevice &dev = CuDevice::Instantiate();
   const bool overlap = overlap_ && !dev.Profiling();
   if (overlap && static_cast<int32>(layer_events_.size()) < L) layer_events_.resize(L, NULL);
-  bool side_used = false;
+  bool side_used = false, aux_used = false;
   // to be called before the back-propagation of layer i is queued
   auto err_ready = [&](int32 i) {
     if (!overlap || !nnet_[i]->IsUpdatable()) return;
@@ -153,9 +154,16 @@ void Nnet::Backpropagate(const CuMatrix<BaseFloat> &in_err, CuMatrix<BaseFloat> 
     if (bl != NULL && bl->UpdateKeepsOldWeights()) {
       // both halves on the side stream: the main stream's chain (back-propagation GEMM, its
       // slab sum) stays as short as possible, since the next layer's pair waits for it
-      CuStreamScope scope(dev.SideStream());
-      bl->UpdateWeights(input, err);
+      {
+        CuStreamScope scope(dev.SideStream());
+        bl->UpdateWeights(input, err);
+      }
+      // the bias half (a small column-sum kernel) on a stream of its own, behind the same
+      // "error ready" point: it neither delays the next update GEMM nor the back-propagation chain
+      CU_SAFE_CALL(hipK_stream_wait_event(dev.AuxStream(), layer_events_[i]));
+      CuStreamScope scope(dev.AuxStream());
       bl->UpdateBias(err);
+      aux_used = true;
       return;
     }
     dev.Order(dev.MainStream(), dev.SideStream(), &layer_events_[i]);
@@ -193,6 +201,7 @@ void Nnet::Backpropagate(const CuMatrix<BaseFloat> &in_err, CuMatrix<BaseFloat> 
     --i;
   }
   if (side_used) dev.Order(dev.SideStream(), dev.MainStream(), &join_event_);
+  if (aux_used) dev.Order(dev.AuxStream(), dev.MainStream(), &aux_join_event_);
 }
 
 void Nnet::Feedforward(const CuMatrix<BaseFloat> &in, CuMatrix<BaseFloat> *out) {

@@ -26,7 +26,7 @@ namespace kaldi {
 
 class Nnet {
  public:
-  Nnet() : learn_rate_(0.0), fusion_(true), overlap_(true), dp_ranks_(1), dp_grad_(NULL), dp_grad_size_(0), join_event_(NULL) {}
+  Nnet() : learn_rate_(0.0), fusion_(true), overlap_(true), dp_ranks_(1), dp_grad_(NULL), dp_grad_size_(0), join_event_(NULL), aux_join_event_(NULL) {}
   ~Nnet();
 
   /// forward pass, keeping every layer's output for Backpropagate
@@ -87,7 +87,7 @@ class Nnet {
   BaseFloat *dp_grad_;   // device staging buffer for one layer's gradient
   size_t dp_grad_size_;
   std::vector<khEvent_t> layer_events_;  // "error of layer i ready, its weights no longer read"
-  khEvent_t join_event_;
+  khEvent_t join_event_, aux_join_event_;
   KALDI_DISALLOW_COPY_AND_ASSIGN(Nnet);
 };
 
