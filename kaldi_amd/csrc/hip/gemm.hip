@@ -32,6 +32,10 @@ int softmax_slabs_launch(hipStream_t st, float *y, int ldy, const float *x, int 
                          const float *bias, int rows, int cols);
 }
 
+#ifndef KH_SCHED
+#define KH_SCHED 0  // 0: memory instructions spread over the MFMA gaps, 1: clustered (see tile_body)
+#endif
+
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -310,12 +314,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
   };
   // one register-staged 16-byte unit of the next tile: registers -> LDS, global -> registers
   constexpr int NC = A_UNITS + B_UNITS;
-  // 16 bytes into LDS as two 8-byte stores: measured beside dependent MFMAs, a ds_write_b128 into
-  // the padded image holds the wave ~59 cycles, the pair of ds_write_b64 ~1
-  auto lds_store16 = [&](float *dst, const float4 &v) {
-    *reinterpret_cast<float2 *>(dst) = make_float2(v.x, v.y);
-    *reinterpret_cast<float2 *>(dst + 2) = make_float2(v.z, v.w);
-  };
+  auto lds_store16 = [&](float *dst, const float4 &v) { *reinterpret_cast<float4 *>(dst) = v; };
   auto write_op = [&](float *base, int c) {
     if (c < A_UNITS) {
       const int unit = tid + c * NT;
@@ -374,7 +373,6 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
   constexpr int G = BK / 8;           // k-groups per tile
   constexpr int MG = 4 * TM * TN;     // MFMAs per group
   static_assert(G >= 4 && G % 2 == 0, "BK must be a multiple of 16, at least 32");
-  constexpr int RPS = (RN + (MG / 2) - 1) / (MG / 2);  // LDS reads per MFMA slot: done by mid-group
   int kt = 0;
   if (nfull == 0) {
     // unaligned operands or a K range shorter than one tile: plain double-buffered loop
@@ -410,7 +408,27 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
     Frag fr[2];
 #pragma unroll
     for (int r = 0; r < RN; ++r) read_op(fr[0], lds, 0, r);
+#if KH_SCHED == 1
+#pragma unroll
+    for (int r = 0; r < RN; ++r) read_op(fr[1], lds, 1, r);
+#endif
 
+    // Measured beside a chain of MFMAs (tools/mfma_probe2.hip): any gap between two MFMAs that holds
+    // other instructions costs ~8 cycles, whatever and however many they are (as long as they
+    // issue within the MFMA's 64 cycles), and an empty gap costs nothing.  So the memory
+    // instructions are clustered: all operand reads of a group sit in ONE gap, the one right
+    // before the group that still has a whole group of MFMAs to go (that gap also takes the
+    // wait for the operands about to be used), and every copy unit gets a gap of its own.
+    //   slot (g, MG-1), i.e. behind the last MFMA of group g: reads of group g+2 into the
+    //     fragment buffer group g has just finished with; for g = G-2 the barrier comes first
+    //     (from there on the reads go to the next tile).
+    //   copy unit c: spread over the other slots of groups 0..G-2 (all stores before the barrier).
+    auto copy_slot = [](int c) {
+      constexpr int AVAIL = (G - 1) * (MG - 1);  // slots of groups 0..G-2 without the read slots
+      const int k = (c * AVAIL) / NC + (AVAIL / NC) / 2;  // even spacing, centred
+      return (k / (MG - 1)) * MG + (k % (MG - 1));
+    };
+    static_assert(NC <= (G - 1) * (MG - 1), "more copy units than free MFMA slots");
     auto tile_body = [&](auto last_tag) {
       constexpr bool LAST = decltype(last_tag)::value;
       float *cur = lds + (kt & 1) * (A_ELEMS + B_ELEMS);
@@ -422,6 +440,27 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
         for (int t = 0; t < MG; ++t) {
           const int j = t / (TM * TN), i = (t % (TM * TN)) / TN, q = t % TN;
           acc[i][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(fr[g & 1].a[i][j], fr[g & 1].b[q][j], acc[i][q], 0, 0, 0);
+#if KH_SCHED == 1
+          if (t == MG - 1) {
+            if (g + 2 < G) {
+#pragma unroll
+              for (int r = 0; r < RN; ++r) read_op(fr[g & 1], cur, g + 2, r);
+            } else if (!LAST) {
+              if (g == G - 2) lds_barrier();
+#pragma unroll
+              for (int r = 0; r < RN; ++r) read_op(fr[g & 1], nxt, g + 2 - G, r);
+            }
+          } else if (!LAST && g <= G - 2) {
+#pragma unroll
+            for (int c = 0; c < NC; ++c)
+              if (copy_slot(c) == g * MG + t) {
+                write_op(nxt, c);
+                load_op(c, kt_load);
+              }
+          }
+#else
+          // reads of group g+1 behind the first MFMAs of group g, copies in the second half of groups 1..G-2
+          constexpr int RPS = (RN + (MG / 2) - 1) / (MG / 2);
           if (g + 1 < G) {
 #pragma unroll
             for (int r = 0; r < RN; ++r)
@@ -433,13 +472,18 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
               if (r / RPS == t) read_op(fr[0], nxt, 0, r);
           }
           if (!LAST && g >= 1 && g <= G - 2) {
+            constexpr int PER = (NC + (G - 2) - 1) / (G - 2);
+            constexpr int STEP = (MG / 2) / PER > 0 ? (MG / 2) / PER : 1;
 #pragma unroll
-            for (int c = 0; c < NC; ++c)
-              if (MG + (c * MG * (G - 2)) / NC == g * MG + t) {
+            for (int c = 0; c < NC; ++c) {
+              const int tt = MG / 2 + (c % PER) * STEP;
+              if ((1 + c / PER) * MG + (tt < MG ? tt : MG - 1) == g * MG + t) {
                 write_op(nxt, c);
                 load_op(c, kt_load);
               }
+            }
           }
+#endif
           __builtin_amdgcn_sched_barrier(0);
         }
       }
@@ -579,7 +623,8 @@ Plan make_plan(int M, int N, int K, int num_cu, bool allow_split, bool always_sl
       const double per_block = mfma > mem ? mfma : mem;
       const double n = ceil(blocks / num_cu);
       // with two or more workgroups on every CU one's stalls are filled by another's MFMAs
-      const double share = blocks >= 2.0 * num_cu ? 0.9 : 1.0;
+      static const double share_f = getenv("KALDI_HIP_GEMM_SHARE") ? atof(getenv("KALDI_HIP_GEMM_SHARE")) : 0.9;
+      const double share = blocks >= 2.0 * num_cu ? share_f : 1.0;
       double cost = (n * per_block * share + t.fixed) / cyc_per_us;
       if (s > 1 || always_slabs) cost += (s + 1.0) * (double)M * N * 4.0 / 3.5e6 + 2.5;
       if (cost < best_cost) {

@@ -8,7 +8,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int PITCH = 36, TILE = 128 * PITCH;  // A(64 rows)+B(64 rows), 32 k + pad
 
-template <bool READS, bool WRITES, bool LOADS, bool BARRIER, int NACC, int WKIND = 0, int DEPTH = 1>
+template <bool READS, bool WRITES, bool LOADS, bool BARRIER, int NACC, int WKIND = 0, int DEPTH = 1, int RKIND = 0, int RPOS = 0>
 __global__ __launch_bounds__(256) void probe(const float *__restrict__ g, float *out, unsigned long long *cyc, int tiles) {
   __shared__ __attribute__((aligned(16))) float lds[2 * TILE];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, li = lane & 31, lh = lane >> 5;
@@ -44,10 +44,24 @@ __global__ __launch_bounds__(256) void probe(const float *__restrict__ g, float 
         const float bv = t == 0 ? fb[gI & 1].x : t == 1 ? fb[gI & 1].y : t == 2 ? fb[gI & 1].z : fb[gI & 1].w;
         acc[(gI * 4 + t) % NACC] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[(gI * 4 + t) % NACC], 0, 0, 0);
         if (BARRIER && gI == 3 && t == 0) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        if (READS && t < 2) {
+        // RPOS: 0 = A behind MFMA 0, B behind MFMA 1; 1 = both behind MFMA 0; 2 = behind MFMAs 2 and 3;
+        //       3 = like 0 plus an early explicit wait behind MFMA 2
+        if (RPOS == 3 && t == 2) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        for (int rr = 0; rr < 2; ++rr)
+        if (READS && ((RPOS == 0 || RPOS == 3) ? (t == rr) : RPOS == 1 ? (t == 0) : (t == 2 + rr))) {
+          const int t = rr;
           const float *src = (gI == 3 ? nxt : cur) + (t == 0 ? a_off : b_off) + ((gI + 1) & 3) * 8;
-          if (t == 0) fa[(gI + 1) & 1] = *reinterpret_cast<const float4 *>(src);
-          else fb[(gI + 1) & 1] = *reinterpret_cast<const float4 *>(src);
+          float4 val;
+          if (RKIND == 0) {
+            val = *reinterpret_cast<const float4 *>(src);
+          } else if (RKIND == 1) {
+            const float2 lo = *reinterpret_cast<const float2 *>(src), hi = *reinterpret_cast<const float2 *>(src + 2);
+            val = make_float4(lo.x, lo.y, hi.x, hi.y);
+          } else {
+            val = make_float4(src[0], src[1], src[2], src[3]);
+          }
+          if (t == 0) fa[(gI + 1) & 1] = val;
+          else fb[(gI + 1) & 1] = val;
         }
         if ((gI == 1 || gI == 2) && (t == 0 || t == 2)) {
           const int c = (gI - 1) * 2 + (t >> 1);
@@ -80,11 +94,11 @@ __global__ __launch_bounds__(256) void probe(const float *__restrict__ g, float 
   if (tid == 0) cyc[blockIdx.x] = t1 - t0;
 }
 
-template <bool READS, bool WRITES, bool LOADS, bool BARRIER, int NACC, int WKIND = 0, int DEPTH = 1>
+template <bool READS, bool WRITES, bool LOADS, bool BARRIER, int NACC, int WKIND = 0, int DEPTH = 1, int RKIND = 0, int RPOS = 0>
 void run(const char *name, const float *g, float *out, unsigned long long *cyc) {
   const int nblk = 256, tiles = 256;
-  probe<READS, WRITES, LOADS, BARRIER, NACC, WKIND, DEPTH><<<nblk, 256>>>(g, out, cyc, tiles);
-  probe<READS, WRITES, LOADS, BARRIER, NACC, WKIND, DEPTH><<<nblk, 256>>>(g, out, cyc, tiles);
+  probe<READS, WRITES, LOADS, BARRIER, NACC, WKIND, DEPTH, RKIND, RPOS><<<nblk, 256>>>(g, out, cyc, tiles);
+  probe<READS, WRITES, LOADS, BARRIER, NACC, WKIND, DEPTH, RKIND, RPOS><<<nblk, 256>>>(g, out, cyc, tiles);
   if (hipDeviceSynchronize() != hipSuccess) printf("launch failed\n");
   std::vector<unsigned long long> h(nblk);
   (void)hipMemcpy(h.data(), cyc, nblk * 8, hipMemcpyDeviceToHost);
@@ -101,21 +115,12 @@ int main() {
   (void)hipMalloc(&out, 256 * 256 * 4);
   (void)hipMalloc(&cyc, 256 * 8);
   run<false, false, false, false, 1>("MFMA chain only", g, out, cyc);
-  run<true, false, false, false, 1>("+ LDS reads feeding it", g, out, cyc);
-  run<true, false, false, true, 1>("+ LDS reads + barrier", g, out, cyc);
-  run<true, true, false, false, 1>("+ LDS reads + LDS stores", g, out, cyc);
-  run<true, true, false, true, 1>("+ LDS reads + LDS stores + barrier", g, out, cyc);
-  run<true, false, true, false, 1>("+ LDS reads + global loads (no stores)", g, out, cyc);
-  run<true, true, true, false, 1>("+ LDS reads + stores + global loads", g, out, cyc);
-  run<true, true, true, true, 1>("everything (as the library kernel)", g, out, cyc);
-  run<true, true, true, true, 4>("everything, 4 independent accumulators", g, out, cyc);
-  run<true, true, false, false, 1, 1>("+ LDS reads + stores as 2 x b64", g, out, cyc);
-  run<true, true, false, false, 1, 2>("+ LDS reads + stores as 4 x b32", g, out, cyc);
-  run<true, true, true, true, 1, 1>("everything, stores as 2 x b64", g, out, cyc);
-  run<true, true, true, true, 1, 2>("everything, stores as 4 x b32", g, out, cyc);
-  run<true, false, false, true, 1, 3>("LDS reads + barrier + direct-to-LDS loads", g, out, cyc);
-  run<true, true, true, true, 1, 1, 2>("everything, 2 x b64 stores, prefetch 2 tiles", g, out, cyc);
-  run<true, true, true, true, 1, 2, 2>("everything, 4 x b32 stores, prefetch 2 tiles", g, out, cyc);
-  run<true, true, true, true, 1, 0, 2>("everything, b128 stores, prefetch 2 tiles", g, out, cyc);
+  run<true, false, false, false, 1>("+ LDS reads b128", g, out, cyc);
+  run<true, false, false, false, 1, 0, 1, 1>("+ LDS reads 2 x b64", g, out, cyc);
+  run<true, false, false, false, 1, 0, 1, 2>("+ LDS reads 4 x b32", g, out, cyc);
+  run<true, false, false, false, 4>("+ LDS reads b128, 4 accumulators", g, out, cyc);
+  run<true, false, false, false, 1, 0, 1, 0, 1>("+ LDS reads both behind MFMA 0", g, out, cyc);
+  run<true, false, false, false, 1, 0, 1, 0, 2>("+ LDS reads behind MFMA 2 and 3", g, out, cyc);
+  run<true, false, false, false, 1, 0, 1, 0, 3>("+ LDS reads, explicit wait behind MFMA 2", g, out, cyc);
   return 0;
 }

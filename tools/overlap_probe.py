@@ -46,7 +46,7 @@ def run(concurrent, iters=20):
     return (time.perf_counter() - t0) / iters * 1e6
 
 
-for plan in [(0, 0, 0), (64, 64, 0), (128, 128, 0)]:
+for plan in [(0, 0, 0), (64, 64, 1), (64, 64, 2), (64, 64, 4), (128, 64, 1), (128, 128, 1), (128, 128, 2)]:
     h.call("hipK_gemm_force_plan", *plan)
     run(False, 3)
     a = run(False)
