@@ -32,6 +32,9 @@ int softmax_slabs_launch(hipStream_t st, float *y, int ldy, const float *x, int 
                          const float *bias, int rows, int cols);
 }
 
+#ifndef KH_PF
+#define KH_PF 1  // K-tiles of global-load prefetch held in registers (1 or 2)
+#endif
 #ifndef KH_SCHED
 #define KH_SCHED 0  // 0: memory instructions spread over the MFMA gaps, 1: clustered (see tile_body)
 #endif
@@ -54,6 +57,7 @@ struct GemmParams {
   int lda, ldb;
   int M, N, K;
   int splitk, k_per_split;
+  int a_bytes, b_bytes;  // operand footprints when both are below 2 GiB (buffer addressing), else 0
   int tiles_m, tiles_n;
   float alpha, beta;
   float *C;
@@ -154,6 +158,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
   const int wm0 = (wid / WAVES_N) * (TM * 32), wn0 = (wid % WAVES_N) * (TN * 32);
 
   float4 ra[A_UNITS], rb[B_UNITS];
+#if KH_PF == 2
+  float4 ra2[A_UNITS], rb2[B_UNITS];  // second register set: the tile after next
+#endif
 
   // Loads of one K-tile into registers, two forms.
   // fast: VEC layout and every k of the tile inside [kbeg,kend).  Unconditional 16-byte loads from
@@ -161,8 +168,15 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
   //   valid one, their products only reach output elements that are never stored -- so all loads
   //   of a tile are in flight together and no wait sits between them.
   // slow: guarded element-wise loads with zero fill (the K-tail tile, unaligned operands).
-  const float *pa[A_UNITS], *pb[B_UNITS];
-  size_t a_step, b_step;  // pointer advance per K-tile
+  // The fast loads are buffer loads: one resource descriptor per operand in SGPRs, a 32-bit byte
+  // offset per thread and unit, the K-tile advance as a scalar offset.  Measured beside MFMAs,
+  // global_load with 64-bit per-lane addresses roughly doubles the cost of a K-tile; the buffer
+  // form is nearly free (tools/mfma_probe2.hip), and out-of-range offsets return 0 instead of faulting.
+  typedef int v4i __attribute__((ext_vector_type(4)));
+  const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc((void *)p.A, 0, p.a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc((void *)p.B, 0, p.b_bytes, 0x00020000);
+  int oa[A_UNITS], ob[B_UNITS];  // byte offsets of this thread's units in K-tile 0
+  int a_step, b_step;            // byte advance per K-tile
   {
     const int a_xlast = ((p.M - 1) >> 2) << 2, b_xlast = ((p.N - 1) >> 2) << 2;
 #pragma unroll
@@ -170,10 +184,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
       const int unit = tid + u * NT;
       if (A_KMAJOR) {
         const int row = unit / (BK / 4), kq = unit % (BK / 4);
-        pa[u] = p.A + (size_t)min(m0 + row, p.M - 1) * p.lda + (kbeg + kq * 4);
+        oa[u] = (min(m0 + row, p.M - 1) * p.lda + (kbeg + kq * 4)) * 4;
       } else {
         const int krow = unit / (BM / 4), mq = unit % (BM / 4);
-        pa[u] = p.A + (size_t)(kbeg + krow) * p.lda + min(m0 + mq * 4, a_xlast);
+        oa[u] = ((kbeg + krow) * p.lda + min(m0 + mq * 4, a_xlast)) * 4;
       }
     }
 #pragma unroll
@@ -181,20 +195,24 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
       const int unit = tid + u * NT;
       if (B_KMAJOR) {
         const int row = unit / (BK / 4), kq = unit % (BK / 4);
-        pb[u] = p.B + (size_t)min(n0 + row, p.N - 1) * p.ldb + (kbeg + kq * 4);
+        ob[u] = (min(n0 + row, p.N - 1) * p.ldb + (kbeg + kq * 4)) * 4;
       } else {
         const int krow = unit / (BN / 4), nq = unit % (BN / 4);
-        pb[u] = p.B + (size_t)(kbeg + krow) * p.ldb + min(n0 + nq * 4, b_xlast);
+        ob[u] = ((kbeg + krow) * p.ldb + min(n0 + nq * 4, b_xlast)) * 4;
       }
     }
-    a_step = A_KMAJOR ? (size_t)BK : (size_t)BK * p.lda;
-    b_step = B_KMAJOR ? (size_t)BK : (size_t)BK * p.ldb;
+    a_step = (A_KMAJOR ? BK : BK * p.lda) * 4;
+    b_step = (B_KMAJOR ? BK : BK * p.ldb) * 4;
   }
+  auto buf_load = [&](const __amdgpu_buffer_rsrc_t &rs, int voff, int soff) {
+    const v4i r = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0);
+    return make_float4(__int_as_float(r.x), __int_as_float(r.y), __int_as_float(r.z), __int_as_float(r.w));
+  };
   auto load_fast = [&](int kt) {
 #pragma unroll
-    for (int u = 0; u < A_UNITS; ++u) ra[u] = *reinterpret_cast<const float4 *>(pa[u] + kt * a_step);
+    for (int u = 0; u < A_UNITS; ++u) ra[u] = buf_load(rsrc_a, oa[u], kt * a_step);
 #pragma unroll
-    for (int u = 0; u < B_UNITS; ++u) rb[u] = *reinterpret_cast<const float4 *>(pb[u] + kt * b_step);
+    for (int u = 0; u < B_UNITS; ++u) rb[u] = buf_load(rsrc_b, ob[u], kt * b_step);
   };
   auto load_slow = [&](int kt) {
     const int k0 = kbeg + kt * BK;
@@ -315,22 +333,34 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
   // one register-staged 16-byte unit of the next tile: registers -> LDS, global -> registers
   constexpr int NC = A_UNITS + B_UNITS;
   auto lds_store16 = [&](float *dst, const float4 &v) { *reinterpret_cast<float4 *>(dst) = v; };
-  auto write_op = [&](float *base, int c) {
+  auto write_op = [&](float *base, int c, int par) {
+#if KH_PF == 2
+    const float4 &va = par ? ra2[c < A_UNITS ? c : 0] : ra[c < A_UNITS ? c : 0];
+    const float4 &vb = par ? rb2[c < A_UNITS ? 0 : c - A_UNITS] : rb[c < A_UNITS ? 0 : c - A_UNITS];
+#else
+    const float4 &va = ra[c < A_UNITS ? c : 0];
+    const float4 &vb = rb[c < A_UNITS ? 0 : c - A_UNITS];
+#endif
     if (c < A_UNITS) {
       const int unit = tid + c * NT;
       const int off = A_KMAJOR ? (unit / (BK / 4)) * PA + (unit % (BK / 4)) * 4 : (unit / (BM / 4)) * PA + (unit % (BM / 4)) * 4;
-      if (A_KMAJOR) lds_store16(base + off, ra[c]);
-      else *reinterpret_cast<float4 *>(base + off) = ra[c];
+      *reinterpret_cast<float4 *>(base + off) = va;
     } else {
       const int unit = tid + (c - A_UNITS) * NT;
       const int off = B_KMAJOR ? (unit / (BK / 4)) * PB + (unit % (BK / 4)) * 4 : (unit / (BN / 4)) * PB + (unit % (BN / 4)) * 4;
-      if (B_KMAJOR) lds_store16(base + A_ELEMS + off, rb[c - A_UNITS]);
-      else *reinterpret_cast<float4 *>(base + A_ELEMS + off) = rb[c - A_UNITS];
+      *reinterpret_cast<float4 *>(base + A_ELEMS + off) = vb;
     }
   };
-  auto load_op = [&](int c, int kt) {
-    if (c < A_UNITS) ra[c] = *reinterpret_cast<const float4 *>(pa[c] + kt * a_step);
-    else rb[c - A_UNITS] = *reinterpret_cast<const float4 *>(pb[c - A_UNITS] + kt * b_step);
+  auto load_op = [&](int c, int kt, int par) {
+    const float4 v = (c < A_UNITS) ? buf_load(rsrc_a, oa[c < A_UNITS ? c : 0], kt * a_step)
+                                   : buf_load(rsrc_b, ob[c < A_UNITS ? 0 : c - A_UNITS], kt * b_step);
+#if KH_PF == 2
+    if (par) {
+      if (c < A_UNITS) ra2[c] = v; else rb2[c - A_UNITS] = v;
+      return;
+    }
+#endif
+    if (c < A_UNITS) ra[c] = v; else rb[c - A_UNITS] = v;
   };
   // MFMAs of one K-tile out of LDS buffer `buf`, unpipelined (K tail, unaligned operands)
   auto compute = [&](int buf) {
@@ -369,7 +399,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
   };
 
   // K-tiles completely inside the split take the fast loads; at most one tail tile does not.
-  const int nfull = VEC ? (kend - kbeg) / BK : 0;
+  const int nfull = (VEC && p.a_bytes > 0) ? (kend - kbeg) / BK : 0;
   constexpr int G = BK / 8;           // k-groups per tile
   constexpr int MG = 4 * TM * TN;     // MFMAs per group
   static_assert(G >= 4 && G % 2 == 0, "BK must be a multiple of 16, at least 32");
@@ -429,11 +459,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
       return (k / (MG - 1)) * MG + (k % (MG - 1));
     };
     static_assert(NC <= (G - 1) * (MG - 1), "more copy units than free MFMA slots");
-    auto tile_body = [&](auto last_tag) {
+    auto tile_body = [&](auto last_tag, auto par_tag) {
       constexpr bool LAST = decltype(last_tag)::value;
+      constexpr int PAR = decltype(par_tag)::value;  // register set this tile stores from and refills
       float *cur = lds + (kt & 1) * (A_ELEMS + B_ELEMS);
       float *nxt = lds + ((kt + 1) & 1) * (A_ELEMS + B_ELEMS);
-      const int kt_load = min(kt + 2, nfull - 1);  // past the end: a harmless repeat of the last tile
+      const int kt_load = min(kt + 1 + KH_PF, nfull - 1);  // past the end: a harmless repeat of the last tile
 #pragma unroll
       for (int g = 0; g < G; ++g) {
 #pragma unroll
@@ -454,8 +485,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
 #pragma unroll
             for (int c = 0; c < NC; ++c)
               if (copy_slot(c) == g * MG + t) {
-                write_op(nxt, c);
-                load_op(c, kt_load);
+                write_op(nxt, c, PAR);
+                load_op(c, kt_load, PAR);
               }
           }
 #else
@@ -478,8 +509,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
             for (int c = 0; c < NC; ++c) {
               const int tt = MG / 2 + (c % PER) * STEP;
               if ((1 + c / PER) * MG + (tt < MG ? tt : MG - 1) == g * MG + t) {
-                write_op(nxt, c);
-                load_op(c, kt_load);
+                write_op(nxt, c, PAR);
+                load_op(c, kt_load, PAR);
               }
             }
           }
@@ -488,7 +519,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
         }
       }
     };
-    for (; kt + 1 < nfull; ++kt) {
+    auto steady = [&](auto par_tag) {
       if (PREFETCH && full_tile) {
 #pragma unroll
         for (int a = 0; a < NPRE; ++a)
@@ -497,12 +528,29 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
             npre = a + 1;
           }
       }
-      tile_body(std::false_type());
+      tile_body(std::false_type(), par_tag);
+    };
+#if KH_PF == 2
+    // two register sets alternate: tile kt stores set kt&1 (holding tile kt+1) and refills it with kt+3
+    if (nfull > 1) {
+#pragma unroll
+      for (int c = 0; c < NC; ++c) load_op(c, min(2, nfull - 1), 1);
     }
+    for (;;) {
+      if (!(kt + 1 < nfull)) break;
+      steady(std::integral_constant<int, 0>());
+      ++kt;
+      if (!(kt + 1 < nfull)) break;
+      steady(std::integral_constant<int, 1>());
+      ++kt;
+    }
+#else
+    for (; kt + 1 < nfull; ++kt) steady(std::integral_constant<int, 0>());
+#endif
     KH_STAMP(4);
     const bool tail = nkt > nfull;  // the K tail, at most one partial tile
     if (tail) load_slow(nfull);
-    tile_body(std::true_type());
+    tile_body(std::true_type(), std::integral_constant<int, 0>());
     if (tail) {
       store_tiles(nfull & 1);
       __syncthreads();
@@ -734,6 +782,14 @@ int run_gemm(khStream_t s, bool a_kmajor, bool b_kmajor, GemmParams p, bool allo
   p.tiles_n = (p.N + bn - 1) / bn;
   p.splitk = plan.splitk;
   p.k_per_split = plan.k_per_split;
+  {
+    // rows x leading dimension of each operand as stored; buffer addressing needs < 2 GiB
+    const double ab = ((double)((a_kmajor ? p.M : p.K) - 1) * p.lda + (a_kmajor ? p.K : p.M)) * 4.0;
+    const double bb = ((double)((b_kmajor ? p.N : p.K) - 1) * p.ldb + (b_kmajor ? p.K : p.N)) * 4.0;
+    const bool ok = ab < 2147483648.0 && bb < 2147483648.0 && p.K > 0;
+    p.a_bytes = ok ? (int)ab : 0;
+    p.b_bytes = ok ? (int)bb : 0;
+  }
   const double flops = 2.0 * p.M * p.N * p.K;
   if (p.splitk == 1 && !softmax) {
     TimedLaunch tl(st, flops);

@@ -8,7 +8,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int PITCH = 36, TILE = 128 * PITCH;  // A(64 rows)+B(64 rows), 32 k + pad
 
-template <bool READS, bool WRITES, bool LOADS, bool BARRIER, int NACC, int WKIND = 0, int DEPTH = 1, int RKIND = 0, int RPOS = 0>
+template <bool READS, bool WRITES, bool LOADS, bool BARRIER, int NACC, int WKIND = 0, int DEPTH = 1, int RKIND = 0, int RPOS = 0, int LKIND = 0, int CLUSTER = 0>
 __global__ __launch_bounds__(256) void probe(const float *__restrict__ g, float *out, unsigned long long *cyc, int tiles) {
   __shared__ __attribute__((aligned(16))) float lds[2 * TILE];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, li = lane & 31, lh = lane >> 5;
@@ -28,6 +28,7 @@ __global__ __launch_bounds__(256) void probe(const float *__restrict__ g, float 
   fb[1] = fb[0];
   for (int c = 0; c < 4; ++c) st[c] = *reinterpret_cast<const float4 *>(gp + c * 1024);
   for (int c = 0; c < 4; ++c) st2[c] = *reinterpret_cast<const float4 *>(gp + c * 1024 + 4096);
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(g + (size_t)blockIdx.x * 4096), 0, 0x7fffffff, 0x00020000);
   const unsigned long long t0 = __builtin_amdgcn_s_memtime();
   for (int kt2 = 0; kt2 < tiles; kt2 += DEPTH)
 #pragma unroll
@@ -63,8 +64,9 @@ __global__ __launch_bounds__(256) void probe(const float *__restrict__ g, float 
           if (t == 0) fa[(gI + 1) & 1] = val;
           else fb[(gI + 1) & 1] = val;
         }
-        if ((gI == 1 || gI == 2) && (t == 0 || t == 2)) {
-          const int c = (gI - 1) * 2 + (t >> 1);
+        for (int c = 0; c < 4; ++c)
+        if (CLUSTER == 0 ? ((gI == 1 || gI == 2) && (t == 0 || t == 2) && c == (gI - 1) * 2 + (t >> 1))
+                         : (gI == 1 && t == 2)) {
           if (WKIND == 3) {
             // one 1 KiB piece per wave straight into LDS (unpadded image; addresses only matter for timing here)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gk + c * 1024),
@@ -79,7 +81,12 @@ __global__ __launch_bounds__(256) void probe(const float *__restrict__ g, float 
             if (WRITES && WKIND == 2) {
               dst[0] = stp[c].x; dst[1] = stp[c].y; dst[2] = stp[c].z; dst[3] = stp[c].w;
             }
-            if (LOADS) stp[c] = *reinterpret_cast<const float4 *>(gk + c * 1024);
+            if (LOADS && LKIND == 0) stp[c] = *reinterpret_cast<const float4 *>(gk + c * 1024);
+            if (LOADS && LKIND == 1) {
+              typedef int v4i __attribute__((ext_vector_type(4)));
+              const v4i r = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(tid * 16 + c * 4096), (int)((kt & 3) * 4194304), 0);
+              stp[c] = make_float4(__int_as_float(r.x), __int_as_float(r.y), __int_as_float(r.z), __int_as_float(r.w));
+            }
           }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -94,11 +101,11 @@ __global__ __launch_bounds__(256) void probe(const float *__restrict__ g, float 
   if (tid == 0) cyc[blockIdx.x] = t1 - t0;
 }
 
-template <bool READS, bool WRITES, bool LOADS, bool BARRIER, int NACC, int WKIND = 0, int DEPTH = 1, int RKIND = 0, int RPOS = 0>
+template <bool READS, bool WRITES, bool LOADS, bool BARRIER, int NACC, int WKIND = 0, int DEPTH = 1, int RKIND = 0, int RPOS = 0, int LKIND = 0, int CLUSTER = 0>
 void run(const char *name, const float *g, float *out, unsigned long long *cyc) {
   const int nblk = 256, tiles = 256;
-  probe<READS, WRITES, LOADS, BARRIER, NACC, WKIND, DEPTH, RKIND, RPOS><<<nblk, 256>>>(g, out, cyc, tiles);
-  probe<READS, WRITES, LOADS, BARRIER, NACC, WKIND, DEPTH, RKIND, RPOS><<<nblk, 256>>>(g, out, cyc, tiles);
+  probe<READS, WRITES, LOADS, BARRIER, NACC, WKIND, DEPTH, RKIND, RPOS, LKIND, CLUSTER><<<nblk, 256>>>(g, out, cyc, tiles);
+  probe<READS, WRITES, LOADS, BARRIER, NACC, WKIND, DEPTH, RKIND, RPOS, LKIND, CLUSTER><<<nblk, 256>>>(g, out, cyc, tiles);
   if (hipDeviceSynchronize() != hipSuccess) printf("launch failed\n");
   std::vector<unsigned long long> h(nblk);
   (void)hipMemcpy(h.data(), cyc, nblk * 8, hipMemcpyDeviceToHost);
@@ -115,12 +122,12 @@ int main() {
   (void)hipMalloc(&out, 256 * 256 * 4);
   (void)hipMalloc(&cyc, 256 * 8);
   run<false, false, false, false, 1>("MFMA chain only", g, out, cyc);
-  run<true, false, false, false, 1>("+ LDS reads b128", g, out, cyc);
-  run<true, false, false, false, 1, 0, 1, 1>("+ LDS reads 2 x b64", g, out, cyc);
-  run<true, false, false, false, 1, 0, 1, 2>("+ LDS reads 4 x b32", g, out, cyc);
-  run<true, false, false, false, 4>("+ LDS reads b128, 4 accumulators", g, out, cyc);
-  run<true, false, false, false, 1, 0, 1, 0, 1>("+ LDS reads both behind MFMA 0", g, out, cyc);
-  run<true, false, false, false, 1, 0, 1, 0, 2>("+ LDS reads behind MFMA 2 and 3", g, out, cyc);
-  run<true, false, false, false, 1, 0, 1, 0, 3>("+ LDS reads, explicit wait behind MFMA 2", g, out, cyc);
+  run<true, true, true, true, 1>("everything (b128 stores, global_load)", g, out, cyc);
+  run<true, true, true, true, 1, 2>("everything, 4 x b32 stores", g, out, cyc);
+  run<true, true, true, true, 1, 0, 1, 0, 0, 1>("everything, b128 stores, buffer_load", g, out, cyc);
+  run<true, true, true, true, 1, 2, 1, 0, 0, 1>("everything, 4 x b32 stores, buffer_load", g, out, cyc);
+  run<true, true, true, true, 1, 0, 1, 0, 0, 0, 1>("everything, b128, all copies in one gap", g, out, cyc);
+  run<true, true, true, true, 1, 2, 1, 0, 0, 1, 1>("everything, b32, buffer_load, one gap", g, out, cyc);
+  run<true, true, true, true, 1, 0, 1, 0, 1>("everything, b128, reads in one gap", g, out, cyc);
   return 0;
 }
