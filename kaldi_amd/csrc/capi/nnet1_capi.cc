@@ -103,9 +103,11 @@ int nnet1_train_bunch(void *h, const float *feats_dev, int ld, int rows, int col
                       int cross_validate) {
   CAPI_TRY
   Trainer *t = static_cast<Trainer *>(h);
-  CopyIn(feats_dev, ld, rows, cols, &t->nnet_in);
-  t->targets.Resize(rows);
-  CU_SAFE_CALL(hipK_memcpy(CuDevice::Instantiate().Stream(), t->targets.Data(), labels_dev, rows * sizeof(int32), 2));
+  // windows onto the caller's rows and labels, the way the tool takes bunches out of its cache
+  // (Cache::GetBunchView); the caller keeps them unchanged until this call's work has finished
+  t->nnet_in.AttachView(const_cast<float *>(feats_dev), rows, cols, ld);
+  t->targets.AttachView(const_cast<int32 *>(labels_dev), rows);
+  t->nnet.SetBorrowInput(true);
   t->nnet.Propagate(t->nnet_in, &t->nnet_out);
   t->xent.EvalVec(t->nnet_out, t->targets, &t->glob_err);
   if (!cross_validate) t->nnet.Backpropagate(t->glob_err, NULL);

@@ -40,13 +40,15 @@ class CuMatrix {
   typedef CuMatrix<Real> ThisType;
 
  public:
-  CuMatrix() : num_rows_(0), num_cols_(0), stride_(0), data_(NULL) {}
-  CuMatrix(MatrixIndexT rows, MatrixIndexT cols) : num_rows_(0), num_cols_(0), stride_(0), data_(NULL) {
+  CuMatrix() : num_rows_(0), num_cols_(0), stride_(0), data_(NULL), owner_(true) {}
+  CuMatrix(MatrixIndexT rows, MatrixIndexT cols) : num_rows_(0), num_cols_(0), stride_(0), data_(NULL), owner_(true) {
     Resize(rows, cols);
   }
-  CuMatrix(ThisType &&o) noexcept : num_rows_(o.num_rows_), num_cols_(o.num_cols_), stride_(o.stride_), data_(o.data_) {
+  CuMatrix(ThisType &&o) noexcept
+      : num_rows_(o.num_rows_), num_cols_(o.num_cols_), stride_(o.stride_), data_(o.data_), owner_(o.owner_) {
     o.num_rows_ = o.num_cols_ = o.stride_ = 0;
     o.data_ = NULL;
+    o.owner_ = true;
   }
   ThisType &operator=(ThisType &&o) noexcept {
     if (this != &o) {
@@ -81,7 +83,7 @@ class CuMatrix {
   /// No-op when the shape is unchanged; otherwise frees, allocates (rows start 256-byte aligned)
   /// and zero-fills, padding included.
   ThisType &Resize(MatrixIndexT rows, MatrixIndexT cols) {
-    if (num_rows_ == rows && num_cols_ == cols) return *this;
+    if (owner_ && num_rows_ == rows && num_cols_ == cols) return *this;  // a view always lets go
     KALDI_ASSERT(rows >= 0 && cols >= 0);
     Destroy();
     if (rows == 0 || cols == 0) return *this;
@@ -96,15 +98,36 @@ class CuMatrix {
     return *this;
   }
   void Destroy() {
-    if (data_) {
+    if (data_ && owner_) {
       // pending kernels may still use the buffer
       CuDevice::Instantiate().Synchronize();
       CU_SAFE_CALL(hipK_free(data_));
     }
     data_ = NULL;
+    owner_ = true;
     num_rows_ = num_cols_ = stride_ = 0;
   }
+  /// Makes this matrix a non-owning window onto rows [row0, row0+rows) of `src` (no copy; not in the
+  /// reference).  It stays valid while `src` keeps its allocation; any Resize to a new shape, or
+  /// CopyFromMat, lets go of the window and allocates as usual.
+  void AttachRows(const ThisType &src, MatrixIndexT row0, MatrixIndexT rows) {
+    KALDI_ASSERT(row0 >= 0 && rows >= 0 && row0 + rows <= src.num_rows_);
+    AttachView(const_cast<Real *>(src.data_) + static_cast<size_t>(row0) * src.stride_, rows, src.num_cols_, src.stride_);
+  }
+  /// Non-owning window onto device memory laid out like a CuMatrix (row pitch `stride` elements).
+  void AttachView(Real *data, MatrixIndexT rows, MatrixIndexT cols, MatrixIndexT stride) {
+    KALDI_ASSERT(rows >= 0 && cols >= 0 && stride >= cols);
+    Destroy();
+    if (rows == 0 || cols == 0) return;
+    data_ = data;
+    num_rows_ = rows;
+    num_cols_ = cols;
+    stride_ = stride;
+    owner_ = false;
+  }
+  bool IsView() const { return !owner_; }
   void Swap(ThisType *o) {
+    std::swap(owner_, o->owner_);
     std::swap(num_rows_, o->num_rows_);
     std::swap(num_cols_, o->num_cols_);
     std::swap(stride_, o->stride_);
@@ -232,6 +255,7 @@ class CuMatrix {
   }
   MatrixIndexT num_rows_, num_cols_, stride_;
   Real *data_;
+  bool owner_;  // false: a window onto memory owned elsewhere (AttachView)
   CuMatrix(const ThisType &) = delete;
   ThisType &operator=(const ThisType &) = delete;
 };

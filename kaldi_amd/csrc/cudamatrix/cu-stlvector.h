@@ -14,8 +14,8 @@ class CuStlVector {
   typedef CuStlVector<IntType> ThisType;
 
  public:
-  CuStlVector() : dim_(0), data_(NULL) {}
-  explicit CuStlVector(size_t dim) : dim_(0), data_(NULL) { Resize(dim); }
+  CuStlVector() : dim_(0), data_(NULL), owner_(true) {}
+  explicit CuStlVector(size_t dim) : dim_(0), data_(NULL), owner_(true) { Resize(dim); }
   ~CuStlVector() { Destroy(); }
 
   size_t Dim() const { return dim_; }
@@ -23,7 +23,7 @@ class CuStlVector {
   IntType *Data() { return data_; }
 
   ThisType &Resize(size_t dim) {
-    if (dim_ == dim) return *this;
+    if (owner_ && dim_ == dim) return *this;
     Destroy();
     if (dim == 0) return *this;
     void *p = NULL;
@@ -34,12 +34,26 @@ class CuStlVector {
     return *this;
   }
   void Destroy() {
-    if (data_) {
+    if (data_ && owner_) {
       CuDevice::Instantiate().Synchronize();
       CU_SAFE_CALL(hipK_free(data_));
     }
     data_ = NULL;
+    owner_ = true;
     dim_ = 0;
+  }
+  /// Non-owning window onto `count` elements of device memory owned elsewhere (no copy; not in the
+  /// reference); Resize to another size lets go of it.
+  void AttachView(IntType *data, size_t count) {
+    Destroy();
+    if (count == 0) return;
+    data_ = data;
+    dim_ = count;
+    owner_ = false;
+  }
+  void AttachRange(const ThisType &src, size_t offset, size_t count) {
+    KALDI_ASSERT(offset + count <= src.dim_);
+    AttachView(const_cast<IntType *>(src.data_) + offset, count);
   }
   ThisType &CopyFromVec(const std::vector<IntType> &src) {
     Resize(src.size());
@@ -68,6 +82,7 @@ class CuStlVector {
   static khStream_t S() { return CuDevice::Instantiate().Stream(); }
   size_t dim_;
   IntType *data_;
+  bool owner_;
   CuStlVector(const ThisType &) = delete;
   ThisType &operator=(const ThisType &) = delete;
 };

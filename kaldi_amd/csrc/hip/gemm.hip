@@ -491,7 +491,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
           }
 #else
           // reads of group g+1 behind the first MFMAs of group g, copies in the second half of groups 1..G-2
+#ifdef KH_RPS_ALL
+          constexpr int RPS = RN;  // all reads of the next group behind the first MFMA
+#else
           constexpr int RPS = (RN + (MG / 2) - 1) / (MG / 2);
+#endif
           if (g + 1 < G) {
 #pragma unroll
             for (int r = 0; r < RN; ++r)

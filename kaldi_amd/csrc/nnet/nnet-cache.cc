@@ -136,4 +136,16 @@ void Cache::GetBunch(CuMatrix<BaseFloat> *features, CuStlVector<int32> *targets)
   Advance();
 }
 
+void Cache::GetBunchView(CuMatrix<BaseFloat> *features, CuStlVector<int32> *targets) {
+  StartEmptying();
+  if (!targets_on_device_) {  // once per cache fill
+    targets_device_.CopyFromVec(randomized_ ? targets_random_ : targets_);
+    targets_on_device_ = true;
+  }
+  const CuMatrix<BaseFloat> &src = randomized_ ? features_random_ : features_;
+  features->AttachRows(src, emptying_pos_, bunchsize_);
+  targets->AttachRange(targets_device_, emptying_pos_, bunchsize_);
+  Advance();
+}
+
 }  // namespace kaldi

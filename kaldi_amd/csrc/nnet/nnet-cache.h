@@ -28,6 +28,9 @@ class Cache {
   void GetBunch(CuMatrix<BaseFloat> *features, std::vector<int32> *targets);
   /// labels delivered as a device vector
   void GetBunch(CuMatrix<BaseFloat> *features, CuStlVector<int32> *targets);
+  /// Like the device-label GetBunch, but hands out windows onto the cache's own rows instead of
+  /// copies: valid until the next AddData / Randomize, and read-only for the caller.
+  void GetBunchView(CuMatrix<BaseFloat> *features, CuStlVector<int32> *targets);
 
   bool Full() { return state_ == FULL; }
   bool Empty() { return state_ == EMPTY || filling_pos_ < bunchsize_; }

@@ -52,7 +52,8 @@ void Nnet::Propagate(const CuMatrix<BaseFloat> &in, CuMatrix<BaseFloat> *out) {
     return;
   }
   KALDI_ASSERT(static_cast<int32>(propagate_buf_.size()) >= L + 1);
-  propagate_buf_[0].CopyFromMat(in);
+  if (borrow_input_) propagate_buf_[0].AttachRows(in, 0, in.NumRows());
+  else propagate_buf_[0].CopyFromMat(in);
   for (int32 i = 0; i < L; ++i) {
     const int act = fusion_ ? ActivationAfter(nnet_, i) : -1;
     if (act >= 0) {

@@ -26,7 +26,7 @@ namespace kaldi {
 
 class Nnet {
  public:
-  Nnet() : learn_rate_(0.0), fusion_(true), overlap_(true), dp_ranks_(1), dp_grad_(NULL), dp_grad_size_(0), join_event_(NULL), aux_join_event_(NULL) {}
+  Nnet() : learn_rate_(0.0), fusion_(true), overlap_(true), borrow_input_(false), dp_ranks_(1), dp_grad_(NULL), dp_grad_size_(0), join_event_(NULL), aux_join_event_(NULL) {}
   ~Nnet();
 
   /// forward pass, keeping every layer's output for Backpropagate
@@ -67,6 +67,9 @@ class Nnet {
   /// stream so that it runs beside the backward pass of the layers below (on by default; the
   /// arithmetic and its order inside every layer are unchanged).
   void SetOverlapUpdates(bool on) { overlap_ = on; }
+  /// Propagate keeps a window onto `in` instead of the reference's copy into its first buffer.
+  /// The caller must then leave `in` alone until Backpropagate has returned.  Off by default.
+  void SetBorrowInput(bool on) { borrow_input_ = on; }
   /// Synchronous data-parallel training over `nranks` processes (one GPU each, communicator set up
   /// with hipK_comm_init): every <biasedlinearity> update becomes gradient -> sum all-reduce ->
   /// identical step on every rank, equal to one process training on the concatenated bunch.
@@ -82,7 +85,7 @@ class Nnet {
   std::vector<CuMatrix<BaseFloat> > propagate_buf_;
   std::vector<CuMatrix<BaseFloat> > backpropagate_buf_;
   BaseFloat learn_rate_;
-  bool fusion_, overlap_;
+  bool fusion_, overlap_, borrow_input_;
   int32 dp_ranks_;
   BaseFloat *dp_grad_;   // device staging buffer for one layer's gradient
   size_t dp_grad_size_;

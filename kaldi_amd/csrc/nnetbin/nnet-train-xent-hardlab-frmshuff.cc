@@ -80,6 +80,9 @@ int main(int argc, char *argv[]) {
     nnet.SetL1Penalty(l1_penalty);
     nnet.SetAverageGrad(average_grad);
     nnet.SetFusion(fused);
+    // fused mode also drops the per-bunch copies: bunches are windows onto the cache and the
+    // network reads its input in place (both stay untouched until Backpropagate has returned)
+    nnet.SetBorrowInput(fused);
     nnet_transf.SetFusion(fused);
     if (dist.num_ranks > 1 && !crossvalidate) nnet.SetDataParallel(dist.num_ranks);
 
@@ -137,7 +140,8 @@ int main(int argc, char *argv[]) {
 
       if (dist.num_ranks == 1) {
         while (!cache.Empty()) {
-          cache.GetBunch(&nnet_in, &targets);
+          if (fused) cache.GetBunchView(&nnet_in, &targets);
+          else cache.GetBunch(&nnet_in, &targets);
           nnet.Propagate(nnet_in, &nnet_out);
           xent.EvalVec(nnet_out, targets, &glob_err);
           if (!crossvalidate) nnet.Backpropagate(glob_err, NULL);
@@ -148,7 +152,8 @@ int main(int argc, char *argv[]) {
         // every rank must take the same number of steps: agree once per cache on the bunch count
         const int64 bunches = DistAllReduce(dist, cache.NumBunches(), 1 /*min*/);
         for (int64 b = 0; b < bunches; ++b) {
-          cache.GetBunch(&nnet_in, &targets);
+          if (fused) cache.GetBunchView(&nnet_in, &targets);
+          else cache.GetBunch(&nnet_in, &targets);
           nnet.Propagate(nnet_in, &nnet_out);
           xent.EvalVec(nnet_out, targets, &glob_err);
           if (!crossvalidate) nnet.Backpropagate(glob_err, NULL);
