@@ -36,7 +36,7 @@ int softmax_slabs_launch(hipStream_t st, float *y, int ldy, const float *x, int 
 #define KH_PF 1  // K-tiles of global-load prefetch held in registers (1 or 2)
 #endif
 #ifndef KH_SCHED
-#define KH_SCHED 0  // 0: memory instructions spread over the MFMA gaps, 1: clustered (see tile_body)
+#define KH_SCHED 3  // K-loop form: 0 group-by-group fragments, 2 whole-tile fragments, 3 whole-tile except in the update GEMMs
 #endif
 
 namespace {
@@ -401,6 +401,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
   // K-tiles completely inside the split take the fast loads; at most one tail tile does not.
   const int nfull = (VEC && p.a_bytes > 0) ? (kend - kbeg) / BK : 0;
   constexpr int G = BK / 8;           // k-groups per tile
+  // which K-loop: whole-tile operand fragments (more registers: 2 waves per SIMD at most) or
+  // group-by-group fragments (the update GEMMs, which run 4 workgroups per CU)
+  constexpr bool kWholeTile = (KH_SCHED == 2) || (KH_SCHED == 3 && EPI != EPI_UPDATE && EPI != EPI_RBM);
   constexpr int MG = 4 * TM * TN;     // MFMAs per group
   static_assert(G >= 4 && G % 2 == 0, "BK must be a multiple of 16, at least 32");
   int kt = 0;
@@ -428,6 +431,88 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
     //     i.e. a whole tile of MFMAs ahead of its use;
     //   * the one barrier per tile follows the first MFMA of the last group, whose operands were
     //     fetched before it; the reads behind it fetch group 0 of the next tile.
+    if constexpr (kWholeTile) {
+    // Whole-tile operand fragments.  The operands of ALL k-groups of a tile are held in registers,
+    // double-buffered across tiles, so a tile is NM = G*MG MFMAs in a row with only
+    //   * one gap per copy unit (LDS store of the next tile + buffer load for the tile after), and
+    //   * behind MFMA SB: the wait for this wave's LDS stores, the barrier, and the LDS reads of
+    //     the whole next tile (8 read instructions per gap, consecutive gaps).
+    // Measured (tools/mfma_probe4.hip): 1068 cycles per 64x64x32 tile against 1024 of MFMA, where
+    // reading group by group takes ~1250.
+    load_fast(0);
+    KH_STAMP(1);
+    store_tiles(0);
+    KH_STAMP(2);
+    __syncthreads();
+    KH_STAMP(3);
+    if (nfull > 1) load_fast(1);
+    Frag fr[2][G];
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+      for (int r = 0; r < RN; ++r) read_op(fr[0][g], lds, g, r);
+    constexpr int NM = G * MG;            // MFMAs per tile
+    constexpr int NREAD = G * RN;         // LDS read instructions per tile
+    constexpr int RGAPS = (NREAD + 7) / 8;
+    constexpr int SB = NM - 2 - RGAPS;    // MFMA slot behind which the barrier and the first reads go
+    static_assert(SB >= 1 + NC, "tile too small for this schedule");
+    auto tile_body = [&](auto last_tag, auto par_tag) {
+      constexpr bool LAST = decltype(last_tag)::value;
+      constexpr int PAR = decltype(par_tag)::value;  // = kt & 1: LDS buffer and fragment set of this tile
+      float *nxt = lds + (PAR ^ 1) * (A_ELEMS + B_ELEMS);
+      const int kt_load = min(kt + 2, nfull - 1);  // past the end: a harmless repeat of the last tile
+#pragma unroll
+      for (int m = 0; m < NM; ++m) {
+        const int g = m / MG, t = m % MG;
+        const int j = t / (TM * TN), i = (t % (TM * TN)) / TN, q = t % TN;
+        acc[i][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(fr[PAR][g].a[i][j], fr[PAR][g].b[q][j], acc[i][q], 0, 0, 0);
+        if (!LAST) {
+#pragma unroll
+          for (int c = 0; c < NC; ++c)
+            if (1 + (c * (SB - 1)) / NC == m) {
+              write_op(nxt, c, 0);
+              load_op(c, kt_load, 0);
+            }
+          if (m >= SB && m < SB + RGAPS) {
+            if (m == SB) lds_barrier();
+#pragma unroll
+            for (int x = (m - SB) * 8; x < (m - SB + 1) * 8 && x < NREAD; ++x)
+              read_op(fr[PAR ^ 1][x / RN], nxt, x / RN, x % RN);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+    auto steady = [&](auto par_tag) {
+      if (PREFETCH && full_tile) {
+#pragma unroll
+        for (int a = 0; a < NPRE; ++a)
+          if (kt == a) {
+            prefetch_acc(a);
+            npre = a + 1;
+          }
+      }
+      tile_body(std::false_type(), par_tag);
+    };
+    for (;;) {
+      if (!(kt + 1 < nfull)) break;
+      steady(std::integral_constant<int, 0>());
+      ++kt;
+      if (!(kt + 1 < nfull)) break;
+      steady(std::integral_constant<int, 1>());
+      ++kt;
+    }
+    KH_STAMP(4);
+    const bool tail = nkt > nfull;  // the K tail, at most one partial tile
+    if (tail) load_slow(nfull);
+    if (kt & 1) tile_body(std::true_type(), std::integral_constant<int, 1>());
+    else tile_body(std::true_type(), std::integral_constant<int, 0>());
+    if (tail) {
+      store_tiles(nfull & 1);
+      __syncthreads();
+      compute(nfull & 1);
+    }
+    } else {
     load_fast(0);
     KH_STAMP(1);
     store_tiles(0);
@@ -559,6 +644,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
       store_tiles(nfull & 1);
       __syncthreads();
       compute(nfull & 1);
+    }
     }
   }
 

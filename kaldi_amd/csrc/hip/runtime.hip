@@ -1,5 +1,6 @@
 // Device selection, memory and copies: what the reference took from the CUDA runtime and
 // cu-device.cc (src/cudamatrix/cu-device.cc:56-210, cu-matrix-inl.h:96-310).
+#include <stdlib.h>
 #include <string.h>
 
 #include "common.h"
@@ -95,7 +96,15 @@ KH_EXPORT int hipK_init(int device_id) {
              chosen, prop.gcnArchName);
     return KH_ERR_INVALID_ARG;
   }
-  KH_HIP(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+  {
+    // the library's default stream carries the chain of dependent kernels: give it the highest
+    // priority, so that its (short) kernels are not queued behind work of the other streams
+    int lo = 0, hi = 0;
+    KH_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    const char *e = getenv("KALDI_HIP_STREAM_PRIO");
+    if (e && atoi(e) == 0) KH_HIP(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+    else KH_HIP(hipStreamCreateWithPriority(&c.stream, hipStreamNonBlocking, hi));
+  }
   c.device = chosen;
   c.num_cu = prop.multiProcessorCount;
   c.initialised = true;
@@ -139,7 +148,11 @@ KH_EXPORT int hipK_stream_create(khStream_t *stream) {
   KH_CHECK_INIT();
   KH_REQUIRE(stream != nullptr);
   hipStream_t s;
-  KH_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+  int lo = 0, hi = 0;
+  KH_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+  const char *e = getenv("KALDI_HIP_STREAM_PRIO");
+  if (e && atoi(e) == 0) KH_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+  else KH_HIP(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, lo));  // lowest: see hipK_init
   *stream = (khStream_t)s;
   return KH_OK;
 }
