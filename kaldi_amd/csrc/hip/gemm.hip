@@ -446,6 +446,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
     __syncthreads();
     KH_STAMP(3);
     if (nfull > 1) load_fast(1);
+#if KH_PF == 2
+    if (nfull > 1) {
+#pragma unroll
+      for (int c = 0; c < NC; ++c) load_op(c, min(2, nfull - 1), 1);
+    }
+#endif
     Frag fr[2][G];
 #pragma unroll
     for (int g = 0; g < G; ++g)
@@ -460,7 +466,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
       constexpr bool LAST = decltype(last_tag)::value;
       constexpr int PAR = decltype(par_tag)::value;  // = kt & 1: LDS buffer and fragment set of this tile
       float *nxt = lds + (PAR ^ 1) * (A_ELEMS + B_ELEMS);
-      const int kt_load = min(kt + 2, nfull - 1);  // past the end: a harmless repeat of the last tile
+      const int kt_load = min(kt + 1 + KH_PF, nfull - 1);  // past the end: a harmless repeat of the last tile
 #pragma unroll
       for (int m = 0; m < NM; ++m) {
         const int g = m / MG, t = m % MG;
@@ -470,11 +476,21 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
 #pragma unroll
           for (int c = 0; c < NC; ++c)
             if (1 + (c * (SB - 1)) / NC == m) {
-              write_op(nxt, c, 0);
-              load_op(c, kt_load, 0);
+#if defined(KH_GEMM_STAMPS) && defined(KH_ABL)
+              // timing ablations of the diagnostic build (wrong results on purpose): 1 no LDS stores, 2 no loads, 3 neither
+              if (KH_ABL != 1 && KH_ABL != 3) write_op(nxt, c, 0);
+              if (KH_ABL != 2 && KH_ABL != 3) load_op(c, kt_load, 0);
+#else
+              write_op(nxt, c, KH_PF == 2 ? PAR : 0);
+              load_op(c, kt_load, KH_PF == 2 ? PAR : 0);
+#endif
             }
           if (m >= SB && m < SB + RGAPS) {
+#if defined(KH_GEMM_STAMPS) && defined(KH_ABL) && KH_ABL >= 4
+            if (m == SB && KH_ABL != 4) lds_barrier();  // 4: no barrier
+#else
             if (m == SB) lds_barrier();
+#endif
 #pragma unroll
             for (int x = (m - SB) * 8; x < (m - SB + 1) * 8 && x < NREAD; ++x)
               read_op(fr[PAR ^ 1][x / RN], nxt, x / RN, x % RN);
@@ -494,19 +510,26 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
       }
       tile_body(std::false_type(), par_tag);
     };
-    for (;;) {
-      if (!(kt + 1 < nfull)) break;
+    // two tiles per trip, no exit in the middle: the fragment sets and accumulators then keep
+    // their registers around the back edge (a mid-loop exit made the compiler copy all of them)
+    while (kt + 2 < nfull) {
       steady(std::integral_constant<int, 0>());
       ++kt;
-      if (!(kt + 1 < nfull)) break;
       steady(std::integral_constant<int, 1>());
       ++kt;
     }
-    KH_STAMP(4);
     const bool tail = nkt > nfull;  // the K tail, at most one partial tile
-    if (tail) load_slow(nfull);
-    if (kt & 1) tile_body(std::true_type(), std::integral_constant<int, 1>());
-    else tile_body(std::true_type(), std::integral_constant<int, 0>());
+    if (kt + 1 < nfull) {           // kt is even here
+      steady(std::integral_constant<int, 0>());
+      ++kt;
+      KH_STAMP(4);
+      if (tail) load_slow(nfull);
+      tile_body(std::true_type(), std::integral_constant<int, 1>());
+    } else {
+      KH_STAMP(4);
+      if (tail) load_slow(nfull);
+      tile_body(std::true_type(), std::integral_constant<int, 0>());
+    }
     if (tail) {
       store_tiles(nfull & 1);
       __syncthreads();
