@@ -784,7 +784,7 @@ Plan make_plan(int M, int N, int K, int num_cu, bool allow_split, bool always_sl
       const double per_block = mfma > mem ? mfma : mem;
       const double n = ceil(blocks / num_cu);
       // with two or more workgroups on every CU one's stalls are filled by another's MFMAs
-      static const double share_f = getenv("KALDI_HIP_GEMM_SHARE") ? atof(getenv("KALDI_HIP_GEMM_SHARE")) : 0.9;
+      static const double share_f = getenv("KALDI_HIP_GEMM_SHARE") ? atof(getenv("KALDI_HIP_GEMM_SHARE")) : 1.0;
       const double share = blocks >= 2.0 * num_cu ? share_f : 1.0;
       double cost = (n * per_block * share + t.fixed) / cyc_per_us;
       if (s > 1 || always_slabs) cost += (s + 1.0) * (double)M * N * 4.0 / 3.5e6 + 2.5;
