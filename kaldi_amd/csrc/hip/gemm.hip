@@ -32,9 +32,6 @@ int softmax_slabs_launch(hipStream_t st, float *y, int ldy, const float *x, int 
                          const float *bias, int rows, int cols);
 }
 
-#ifndef KH_PF
-#define KH_PF 1  // K-tiles of global-load prefetch held in registers (1 or 2)
-#endif
 #ifndef KH_SCHED
 #define KH_SCHED 3  // K-loop form: 0 group-by-group fragments, 2 whole-tile fragments, 3 whole-tile except in the update GEMMs
 #endif
@@ -158,9 +155,6 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
   const int wm0 = (wid / WAVES_N) * (TM * 32), wn0 = (wid % WAVES_N) * (TN * 32);
 
   float4 ra[A_UNITS], rb[B_UNITS];
-#if KH_PF == 2
-  float4 ra2[A_UNITS], rb2[B_UNITS];  // second register set: the tile after next
-#endif
 
   // Loads of one K-tile into registers, two forms.
   // fast: VEC layout and every k of the tile inside [kbeg,kend).  Unconditional 16-byte loads from
@@ -332,15 +326,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
   };
   // one register-staged 16-byte unit of the next tile: registers -> LDS, global -> registers
   constexpr int NC = A_UNITS + B_UNITS;
-  auto lds_store16 = [&](float *dst, const float4 &v) { *reinterpret_cast<float4 *>(dst) = v; };
-  auto write_op = [&](float *base, int c, int par) {
-#if KH_PF == 2
-    const float4 &va = par ? ra2[c < A_UNITS ? c : 0] : ra[c < A_UNITS ? c : 0];
-    const float4 &vb = par ? rb2[c < A_UNITS ? 0 : c - A_UNITS] : rb[c < A_UNITS ? 0 : c - A_UNITS];
-#else
+  auto write_op = [&](float *base, int c) {
     const float4 &va = ra[c < A_UNITS ? c : 0];
     const float4 &vb = rb[c < A_UNITS ? 0 : c - A_UNITS];
-#endif
     if (c < A_UNITS) {
       const int unit = tid + c * NT;
       const int off = A_KMAJOR ? (unit / (BK / 4)) * PA + (unit % (BK / 4)) * 4 : (unit / (BM / 4)) * PA + (unit % (BM / 4)) * 4;
@@ -351,15 +339,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
       *reinterpret_cast<float4 *>(base + A_ELEMS + off) = vb;
     }
   };
-  auto load_op = [&](int c, int kt, int par) {
+  auto load_op = [&](int c, int kt) {
     const float4 v = (c < A_UNITS) ? buf_load(rsrc_a, oa[c < A_UNITS ? c : 0], kt * a_step)
                                    : buf_load(rsrc_b, ob[c < A_UNITS ? 0 : c - A_UNITS], kt * b_step);
-#if KH_PF == 2
-    if (par) {
-      if (c < A_UNITS) ra2[c] = v; else rb2[c - A_UNITS] = v;
-      return;
-    }
-#endif
     if (c < A_UNITS) ra[c] = v; else rb[c - A_UNITS] = v;
   };
   // MFMAs of one K-tile out of LDS buffer `buf`, unpipelined (K tail, unaligned operands)
@@ -422,15 +404,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
       __syncthreads();
     }
   } else {
-    // Software pipeline inside the wave (one wave per SIMD has nobody else to hide its latencies).
-    // Every MFMA is followed by at most a few memory instructions, pinned there with scheduling
-    // barriers so that they issue in the shadow of that MFMA:
-    //   * the LDS reads of k-group g+1 go behind the first MFMAs of group g;
-    //   * the next tile moves registers -> other LDS buffer unit by unit during groups 1..G-2,
-    //     each unit's global load for the tile after that re-issued right behind its LDS store,
-    //     i.e. a whole tile of MFMAs ahead of its use;
-    //   * the one barrier per tile follows the first MFMA of the last group, whose operands were
-    //     fetched before it; the reads behind it fetch group 0 of the next tile.
+    // Software pipeline inside the wave (one wave per SIMD has nobody else to hide its latencies):
+    // the memory instructions of the NEXT tiles are placed one by one behind the MFMAs of this
+    // one and pinned there with scheduling barriers, so that they issue in the MFMAs' shadow.
+    // Measured beside a chain of MFMAs (tools/mfma_probe2.hip, mfma_probe4.hip): a gap between two
+    // MFMAs that holds other instructions costs ~8 cycles whatever is in it (as long as it issues
+    // within the MFMA's 64 cycles), an empty gap nothing.  Two forms follow.
     if constexpr (kWholeTile) {
     // Whole-tile operand fragments.  The operands of ALL k-groups of a tile are held in registers,
     // double-buffered across tiles, so a tile is NM = G*MG MFMAs in a row with only
@@ -446,12 +425,6 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
     __syncthreads();
     KH_STAMP(3);
     if (nfull > 1) load_fast(1);
-#if KH_PF == 2
-    if (nfull > 1) {
-#pragma unroll
-      for (int c = 0; c < NC; ++c) load_op(c, min(2, nfull - 1), 1);
-    }
-#endif
     Frag fr[2][G];
 #pragma unroll
     for (int g = 0; g < G; ++g)
@@ -466,7 +439,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
       constexpr bool LAST = decltype(last_tag)::value;
       constexpr int PAR = decltype(par_tag)::value;  // = kt & 1: LDS buffer and fragment set of this tile
       float *nxt = lds + (PAR ^ 1) * (A_ELEMS + B_ELEMS);
-      const int kt_load = min(kt + 1 + KH_PF, nfull - 1);  // past the end: a harmless repeat of the last tile
+      const int kt_load = min(kt + 2, nfull - 1);  // past the end: a harmless repeat of the last tile
 #pragma unroll
       for (int m = 0; m < NM; ++m) {
         const int g = m / MG, t = m % MG;
@@ -478,11 +451,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
             if (1 + (c * (SB - 1)) / NC == m) {
 #if defined(KH_GEMM_STAMPS) && defined(KH_ABL)
               // timing ablations of the diagnostic build (wrong results on purpose): 1 no LDS stores, 2 no loads, 3 neither
-              if (KH_ABL != 1 && KH_ABL != 3) write_op(nxt, c, 0);
-              if (KH_ABL != 2 && KH_ABL != 3) load_op(c, kt_load, 0);
+              if (KH_ABL != 1 && KH_ABL != 3) write_op(nxt, c);
+              if (KH_ABL != 2 && KH_ABL != 3) load_op(c, kt_load);
 #else
-              write_op(nxt, c, KH_PF == 2 ? PAR : 0);
-              load_op(c, kt_load, KH_PF == 2 ? PAR : 0);
+              write_op(nxt, c);
+              load_op(c, kt_load);
 #endif
             }
           if (m >= SB && m < SB + RGAPS) {
@@ -546,64 +519,24 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
     Frag fr[2];
 #pragma unroll
     for (int r = 0; r < RN; ++r) read_op(fr[0], lds, 0, r);
-#if KH_SCHED == 1
-#pragma unroll
-    for (int r = 0; r < RN; ++r) read_op(fr[1], lds, 1, r);
-#endif
 
-    // Measured beside a chain of MFMAs (tools/mfma_probe2.hip): any gap between two MFMAs that holds
-    // other instructions costs ~8 cycles, whatever and however many they are (as long as they
-    // issue within the MFMA's 64 cycles), and an empty gap costs nothing.  So the memory
-    // instructions are clustered: all operand reads of a group sit in ONE gap, the one right
-    // before the group that still has a whole group of MFMAs to go (that gap also takes the
-    // wait for the operands about to be used), and every copy unit gets a gap of its own.
-    //   slot (g, MG-1), i.e. behind the last MFMA of group g: reads of group g+2 into the
-    //     fragment buffer group g has just finished with; for g = G-2 the barrier comes first
-    //     (from there on the reads go to the next tile).
-    //   copy unit c: spread over the other slots of groups 0..G-2 (all stores before the barrier).
-    auto copy_slot = [](int c) {
-      constexpr int AVAIL = (G - 1) * (MG - 1);  // slots of groups 0..G-2 without the read slots
-      const int k = (c * AVAIL) / NC + (AVAIL / NC) / 2;  // even spacing, centred
-      return (k / (MG - 1)) * MG + (k % (MG - 1));
-    };
-    static_assert(NC <= (G - 1) * (MG - 1), "more copy units than free MFMA slots");
-    auto tile_body = [&](auto last_tag, auto par_tag) {
+    // Group-by-group fragments (the update GEMMs): two fragment buffers; the LDS reads of group
+    // g+1 go behind the first MFMAs of group g, the copy units behind the MFMAs of the second half
+    // of groups 1..G-2 (an LDS store never sits in the queue in front of the next group's
+    // operand reads), the one barrier per tile behind the first MFMA of the last group.
+    auto tile_body = [&](auto last_tag) {
       constexpr bool LAST = decltype(last_tag)::value;
-      constexpr int PAR = decltype(par_tag)::value;  // register set this tile stores from and refills
       float *cur = lds + (kt & 1) * (A_ELEMS + B_ELEMS);
       float *nxt = lds + ((kt + 1) & 1) * (A_ELEMS + B_ELEMS);
-      const int kt_load = min(kt + 1 + KH_PF, nfull - 1);  // past the end: a harmless repeat of the last tile
+      const int kt_load = min(kt + 2, nfull - 1);  // past the end: a harmless repeat of the last tile
 #pragma unroll
       for (int g = 0; g < G; ++g) {
 #pragma unroll
         for (int t = 0; t < MG; ++t) {
           const int j = t / (TM * TN), i = (t % (TM * TN)) / TN, q = t % TN;
           acc[i][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(fr[g & 1].a[i][j], fr[g & 1].b[q][j], acc[i][q], 0, 0, 0);
-#if KH_SCHED == 1
-          if (t == MG - 1) {
-            if (g + 2 < G) {
-#pragma unroll
-              for (int r = 0; r < RN; ++r) read_op(fr[g & 1], cur, g + 2, r);
-            } else if (!LAST) {
-              if (g == G - 2) lds_barrier();
-#pragma unroll
-              for (int r = 0; r < RN; ++r) read_op(fr[g & 1], nxt, g + 2 - G, r);
-            }
-          } else if (!LAST && g <= G - 2) {
-#pragma unroll
-            for (int c = 0; c < NC; ++c)
-              if (copy_slot(c) == g * MG + t) {
-                write_op(nxt, c, PAR);
-                load_op(c, kt_load, PAR);
-              }
-          }
-#else
           // reads of group g+1 behind the first MFMAs of group g, copies in the second half of groups 1..G-2
-#ifdef KH_RPS_ALL
-          constexpr int RPS = RN;  // all reads of the next group behind the first MFMA
-#else
           constexpr int RPS = (RN + (MG / 2) - 1) / (MG / 2);
-#endif
           if (g + 1 < G) {
 #pragma unroll
             for (int r = 0; r < RN; ++r)
@@ -621,17 +554,16 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
             for (int c = 0; c < NC; ++c) {
               const int tt = MG / 2 + (c % PER) * STEP;
               if ((1 + c / PER) * MG + (tt < MG ? tt : MG - 1) == g * MG + t) {
-                write_op(nxt, c, PAR);
-                load_op(c, kt_load, PAR);
+                write_op(nxt, c);
+                load_op(c, kt_load);
               }
             }
           }
-#endif
           __builtin_amdgcn_sched_barrier(0);
         }
       }
     };
-    auto steady = [&](auto par_tag) {
+    auto steady = [&]() {
       if (PREFETCH && full_tile) {
 #pragma unroll
         for (int a = 0; a < NPRE; ++a)
@@ -640,29 +572,13 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
             npre = a + 1;
           }
       }
-      tile_body(std::false_type(), par_tag);
+      tile_body(std::false_type());
     };
-#if KH_PF == 2
-    // two register sets alternate: tile kt stores set kt&1 (holding tile kt+1) and refills it with kt+3
-    if (nfull > 1) {
-#pragma unroll
-      for (int c = 0; c < NC; ++c) load_op(c, min(2, nfull - 1), 1);
-    }
-    for (;;) {
-      if (!(kt + 1 < nfull)) break;
-      steady(std::integral_constant<int, 0>());
-      ++kt;
-      if (!(kt + 1 < nfull)) break;
-      steady(std::integral_constant<int, 1>());
-      ++kt;
-    }
-#else
-    for (; kt + 1 < nfull; ++kt) steady(std::integral_constant<int, 0>());
-#endif
+    for (; kt + 1 < nfull; ++kt) steady();
     KH_STAMP(4);
     const bool tail = nkt > nfull;  // the K tail, at most one partial tile
     if (tail) load_slow(nfull);
-    tile_body(std::true_type(), std::integral_constant<int, 0>());
+    tile_body(std::true_type());
     if (tail) {
       store_tiles(nfull & 1);
       __syncthreads();
