@@ -84,22 +84,40 @@ struct GemmParams {
 #define KH_STAMP(i) do { } while (0)
 #endif
 
+// The epilogue's second operand of one output element, fetched before any store so that the
+// loads of all elements of a lane are in flight together: the bias of the column, or y.  Row and
+// column are clamped into the matrix (elements outside are computed but never stored).
 template <int EPI>
-__device__ __forceinline__ void epi_store(const GemmParams &p, int row, int col, float acc, int ks) {
+__device__ __forceinline__ float epi_aux(const GemmParams &p, int row, int col) {
+  if (EPI == EPI_BIAS_ACT) return p.bias[min(col, p.N - 1)];
+  if (EPI == EPI_DSIG) return p.y[(size_t)min(row, p.M - 1) * p.ldy + min(col, p.N - 1)];
+  return 0.f;
+}
+
+// The arithmetic of the epilogue that needs no memory: done for every element of a lane before
+// the guarded stores, so the wait for the operand loads happens once, not in front of every store
+// (where it would also wait for the store before it).
+template <int EPI>
+__device__ __forceinline__ float epi_value(const GemmParams &p, float acc, float aux) {
+  if (EPI == EPI_BIAS_ACT) {
+    const float v = acc + aux;
+    return p.act == KH_ACT_SIGMOID ? kh::sigmoidf(v) : v;
+  }
+  if (EPI == EPI_DSIG) return aux * (1.0f - aux) * acc;
+  return acc;
+}
+
+template <int EPI>
+__device__ __forceinline__ void epi_store(const GemmParams &p, int row, int col, float val, int ks) {
   if (EPI == EPI_SLAB) {
-    p.C[(size_t)ks * p.slab_stride + (size_t)row * p.ldc + col] = acc;
+    p.C[(size_t)ks * p.slab_stride + (size_t)row * p.ldc + col] = val;
   } else if (EPI == EPI_AXPBY) {
     float *c = p.C + (size_t)row * p.ldc + col;
-    *c = (p.beta == 0.f) ? p.alpha * acc : p.alpha * acc + p.beta * *c;
-  } else if (EPI == EPI_BIAS_ACT) {
-    float v = acc + p.bias[col];
-    if (p.act == KH_ACT_SIGMOID) v = kh::sigmoidf(v);
-    p.C[(size_t)row * p.ldc + col] = v;
-  } else if (EPI == EPI_DSIG) {
-    const float yv = p.y[(size_t)row * p.ldy + col];
-    p.C[(size_t)row * p.ldc + col] = yv * (1.0f - yv) * acc;
+    *c = (p.beta == 0.f) ? p.alpha * val : p.alpha * val + p.beta * *c;
+  } else if (EPI == EPI_BIAS_ACT || EPI == EPI_DSIG) {
+    p.C[(size_t)row * p.ldc + col] = val;
   } else if (EPI == EPI_UPDATE) {
-    float c = p.alpha * acc;
+    float c = p.alpha * val;
     if (p.mom != 0.f) c += p.mom * p.C[(size_t)row * p.ldc + col];
     if (p.C) p.C[(size_t)row * p.ldc + col] = c;
     float wv = p.W[(size_t)row * p.ldw + col];
@@ -108,27 +126,35 @@ __device__ __forceinline__ void epi_store(const GemmParams &p, int row, int col,
   } else if (EPI == EPI_RBM) {
     float *dw = p.C + (size_t)row * p.ldc + col;
     const float wv = p.W[(size_t)row * p.ldw + col];
-    float d = p.alpha * acc + *dw;
+    float d = p.alpha * val + *dw;
     d = -p.l2 * wv + d;
     *dw = d;
     p.Wout[(size_t)row * p.ldwout + col] = d + wv;
   }
 }
 
-// BM x BN output tile, BK-deep K-tiles, WAVES_M x WAVES_N waves (always 4 here).
+// BM x BN output tile, 4 waves arranged WAVES_M x WAVES_N x WK.  A K-tile is BKT = BK*WK deep and
+// wave-slice wk of it (BK = 32 k) goes to the waves with that wk: with WK > 1 the waves of a
+// workgroup split K among themselves and add their accumulators through LDS before the epilogue.
+// That keeps 256 workgroups (one per CU) on a 256-row x 2048-column product with 32x64 tiles and
+// the whole K inside the workgroup, so the epilogue can finish the element (bias, sigmoid, ...)
+// instead of writing a partial slab for a second kernel.
 // A_KMAJOR: A(m,k) at A[m*lda+k] (k contiguous), otherwise A[k*lda+m].  Same for B with n.
 // VEC: every row base is 16-byte aligned and leading dimensions are multiples of 4 floats.
-template <int BM, int BN, int BK, bool A_KMAJOR, bool B_KMAJOR, int EPI, bool VEC>
+template <int BM, int BN, int BK, int WK, bool A_KMAJOR, bool B_KMAJOR, int EPI, bool VEC>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
   constexpr int NT = 256;
-  constexpr int WAVES_M = 2, WAVES_N = 2;
+  constexpr int WAVES_M = (WK == 1) ? 2 : 1, WAVES_N = (WK == 4) ? 1 : 2;
+  static_assert(WAVES_M * WAVES_N * WK == 4, "4 waves per workgroup");
+  constexpr int BKT = BK * WK;                          // K depth of one staged tile
   constexpr int TM = BM / (WAVES_M * 32), TN = BN / (WAVES_N * 32);
-  constexpr int PA = A_KMAJOR ? (BK + 4) : BM;         // LDS pitch of the A image (floats)
-  constexpr int PB = B_KMAJOR ? (BK + 4) : BN;
-  constexpr int A_ELEMS = A_KMAJOR ? BM * PA : BK * PA;
-  constexpr int B_ELEMS = B_KMAJOR ? BN * PB : BK * PB;
-  constexpr int A_UNITS = BM * BK / 4 / NT;            // float4 loads per thread per K-tile
-  constexpr int B_UNITS = BN * BK / 4 / NT;
+  static_assert(TM >= 1 && TN >= 1, "tile too small for this wave arrangement");
+  constexpr int PA = A_KMAJOR ? (BKT + 4) : BM;        // LDS pitch of the A image (floats)
+  constexpr int PB = B_KMAJOR ? (BKT + 4) : BN;
+  constexpr int A_ELEMS = A_KMAJOR ? BM * PA : BKT * PA;
+  constexpr int B_ELEMS = B_KMAJOR ? BN * PB : BKT * PB;
+  constexpr int A_UNITS = BM * BKT / 4 / NT;           // float4 loads per thread per K-tile
+  constexpr int B_UNITS = BN * BKT / 4 / NT;
   static_assert(A_UNITS >= 1 && B_UNITS >= 1, "tile too small for 256 threads");
 
   __shared__ __attribute__((aligned(16))) float lds[2 * (A_ELEMS + B_ELEMS)];
@@ -147,12 +173,13 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
   const int m0 = mi * BM, n0 = ni * BN;
   const int kbeg = ks * p.k_per_split;
   const int kend = min(p.K, kbeg + p.k_per_split);
-  const int nkt = (kend - kbeg + BK - 1) / BK;
+  const int nkt = (kend - kbeg + BKT - 1) / BKT;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wid = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
-  const int wm0 = (wid / WAVES_N) * (TM * 32), wn0 = (wid % WAVES_N) * (TN * 32);
+  const int wk = wid / (WAVES_M * WAVES_N);  // which K slice of every tile this wave multiplies
+  const int wm0 = ((wid / WAVES_N) % WAVES_M) * (TM * 32), wn0 = (wid % WAVES_N) * (TN * 32);
 
   float4 ra[A_UNITS], rb[B_UNITS];
 
@@ -177,7 +204,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
     for (int u = 0; u < A_UNITS; ++u) {
       const int unit = tid + u * NT;
       if (A_KMAJOR) {
-        const int row = unit / (BK / 4), kq = unit % (BK / 4);
+        const int row = unit / (BKT / 4), kq = unit % (BKT / 4);
         oa[u] = (min(m0 + row, p.M - 1) * p.lda + (kbeg + kq * 4)) * 4;
       } else {
         const int krow = unit / (BM / 4), mq = unit % (BM / 4);
@@ -188,15 +215,15 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
     for (int u = 0; u < B_UNITS; ++u) {
       const int unit = tid + u * NT;
       if (B_KMAJOR) {
-        const int row = unit / (BK / 4), kq = unit % (BK / 4);
+        const int row = unit / (BKT / 4), kq = unit % (BKT / 4);
         ob[u] = (min(n0 + row, p.N - 1) * p.ldb + (kbeg + kq * 4)) * 4;
       } else {
         const int krow = unit / (BN / 4), nq = unit % (BN / 4);
         ob[u] = ((kbeg + krow) * p.ldb + min(n0 + nq * 4, b_xlast)) * 4;
       }
     }
-    a_step = (A_KMAJOR ? BK : BK * p.lda) * 4;
-    b_step = (B_KMAJOR ? BK : BK * p.ldb) * 4;
+    a_step = (A_KMAJOR ? BKT : BKT * p.lda) * 4;
+    b_step = (B_KMAJOR ? BKT : BKT * p.ldb) * 4;
   }
   auto buf_load = [&](const __amdgpu_buffer_rsrc_t &rs, int voff, int soff) {
     const v4i r = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0);
@@ -209,13 +236,13 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
     for (int u = 0; u < B_UNITS; ++u) rb[u] = buf_load(rsrc_b, ob[u], kt * b_step);
   };
   auto load_slow = [&](int kt) {
-    const int k0 = kbeg + kt * BK;
+    const int k0 = kbeg + kt * BKT;
 #pragma unroll
     for (int u = 0; u < A_UNITS; ++u) {
       const int unit = tid + u * NT;
       float v[4] = {0.f, 0.f, 0.f, 0.f};
       if (A_KMAJOR) {
-        const int row = unit / (BK / 4), kq = unit % (BK / 4);
+        const int row = unit / (BKT / 4), kq = unit % (BKT / 4);
         const int m = m0 + row, k = k0 + kq * 4;
         if (m < p.M) {
           const float *src = p.A + (size_t)m * p.lda + k;
@@ -240,7 +267,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
       const int unit = tid + u * NT;
       float v[4] = {0.f, 0.f, 0.f, 0.f};
       if (B_KMAJOR) {
-        const int row = unit / (BK / 4), kq = unit % (BK / 4);
+        const int row = unit / (BKT / 4), kq = unit % (BKT / 4);
         const int n = n0 + row, k = k0 + kq * 4;
         if (n < p.N) {
           const float *src = p.B + (size_t)n * p.ldb + k;
@@ -268,7 +295,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
     for (int u = 0; u < A_UNITS; ++u) {
       const int unit = tid + u * NT;
       if (A_KMAJOR) {
-        const int row = unit / (BK / 4), kq = unit % (BK / 4);
+        const int row = unit / (BKT / 4), kq = unit % (BKT / 4);
         *reinterpret_cast<float4 *>(As + row * PA + kq * 4) = ra[u];
       } else {
         const int krow = unit / (BM / 4), mq = unit % (BM / 4);
@@ -279,7 +306,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
     for (int u = 0; u < B_UNITS; ++u) {
       const int unit = tid + u * NT;
       if (B_KMAJOR) {
-        const int row = unit / (BK / 4), kq = unit % (BK / 4);
+        const int row = unit / (BKT / 4), kq = unit % (BKT / 4);
         *reinterpret_cast<float4 *>(Bs + row * PB + kq * 4) = rb[u];
       } else {
         const int krow = unit / (BN / 4), nq = unit % (BN / 4);
@@ -304,8 +331,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
     float a[TM][4], b[TN][4];
   };
   constexpr int RN_A = A_KMAJOR ? TM : 4 * TM, RN_B = B_KMAJOR ? TN : 4 * TN, RN = RN_A + RN_B;
-  const int a_lds = A_KMAJOR ? (wm0 + li) * PA + lh * 4 : lh * 4 * PA + wm0 + li;
-  const int b_lds = A_ELEMS + (B_KMAJOR ? (wn0 + li) * PB + lh * 4 : lh * 4 * PB + wn0 + li);
+  const int a_lds = A_KMAJOR ? (wm0 + li) * PA + wk * BK + lh * 4 : (wk * BK + lh * 4) * PA + wm0 + li;
+  const int b_lds = A_ELEMS + (B_KMAJOR ? (wn0 + li) * PB + wk * BK + lh * 4 : (wk * BK + lh * 4) * PB + wn0 + li);
   auto read_op = [&](Frag &f, const float *base, int g, int r) {
     if (r < RN_A) {
       if (A_KMAJOR) {
@@ -331,11 +358,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
     const float4 &vb = rb[c < A_UNITS ? 0 : c - A_UNITS];
     if (c < A_UNITS) {
       const int unit = tid + c * NT;
-      const int off = A_KMAJOR ? (unit / (BK / 4)) * PA + (unit % (BK / 4)) * 4 : (unit / (BM / 4)) * PA + (unit % (BM / 4)) * 4;
+      const int off = A_KMAJOR ? (unit / (BKT / 4)) * PA + (unit % (BKT / 4)) * 4 : (unit / (BM / 4)) * PA + (unit % (BM / 4)) * 4;
       *reinterpret_cast<float4 *>(base + off) = va;
     } else {
       const int unit = tid + (c - A_UNITS) * NT;
-      const int off = B_KMAJOR ? (unit / (BK / 4)) * PB + (unit % (BK / 4)) * 4 : (unit / (BN / 4)) * PB + (unit % (BN / 4)) * 4;
+      const int off = B_KMAJOR ? (unit / (BKT / 4)) * PB + (unit % (BKT / 4)) * 4 : (unit / (BN / 4)) * PB + (unit % (BN / 4)) * 4;
       *reinterpret_cast<float4 *>(base + A_ELEMS + off) = vb;
     }
   };
@@ -369,6 +396,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
   // accumulator's worth per K-tile, so that the read-modify-write at the end starts with the old
   // weights already in registers instead of every workgroup hitting HBM at the same moment.
   constexpr bool PREFETCH = (EPI == EPI_UPDATE);
+  static_assert(!(PREFETCH && WK > 1), "the update epilogue is not built for K split over waves");
   constexpr int NPRE = PREFETCH ? TM * TN : 1;
   float pre[NPRE][16];
   const bool full_tile = (m0 + BM <= p.M) && (n0 + BN <= p.N);
@@ -381,7 +409,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
   };
 
   // K-tiles completely inside the split take the fast loads; at most one tail tile does not.
-  const int nfull = (VEC && p.a_bytes > 0) ? (kend - kbeg) / BK : 0;
+  const int nfull = (VEC && p.a_bytes > 0) ? (kend - kbeg) / BKT : 0;
   constexpr int G = BK / 8;           // k-groups per tile
   // which K-loop: whole-tile operand fragments (more registers: 2 waves per SIMD at most) or
   // group-by-group fragments (the update GEMMs, which run 4 workgroups per CU)
@@ -589,26 +617,80 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
 
   KH_STAMP(5);
   // ---- epilogue: accumulator register r of lane (li, lh) is C[(r&3) + 8*(r>>2) + 4*lh][li] ------
+  if constexpr (WK == 1) {
 #pragma unroll
-  for (int i = 0; i < TM; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int q = 0; q < TN; ++q)
+      for (int q = 0; q < TN; ++q)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        const int col = n0 + wn0 + q * 32 + li;
-        if (PREFETCH && i * TN + q < npre) {
-          // full tile, old weight already here (same arithmetic as epi_store<EPI_UPDATE>)
-          float c = p.alpha * acc[i][q][r];
-          if (p.mom != 0.f) c += p.mom * p.C[(size_t)row * p.ldc + col];
-          if (p.C) p.C[(size_t)row * p.ldc + col] = c;
-          float wv = pre[PREFETCH ? i * TN + q : 0][r];
-          if (p.l2 != 0.f) wv = -p.l2 * wv + wv;
-          p.Wout[(size_t)row * p.ldwout + col] = -p.lr * c + wv;
-        } else if (row < p.M && col < p.N) {
-          epi_store<EPI>(p, row, col, acc[i][q][r], ks);
+        for (int r = 0; r < 16; ++r) {
+          const int row = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          const int col = n0 + wn0 + q * 32 + li;
+          if (PREFETCH && i * TN + q < npre) {
+            // full tile, old weight already here (same arithmetic as epi_store<EPI_UPDATE>)
+            float c = p.alpha * acc[i][q][r];
+            if (p.mom != 0.f) c += p.mom * p.C[(size_t)row * p.ldc + col];
+            if (p.C) p.C[(size_t)row * p.ldc + col] = c;
+            float wv = pre[PREFETCH ? i * TN + q : 0][r];
+            if (p.l2 != 0.f) wv = -p.l2 * wv + wv;
+            p.Wout[(size_t)row * p.ldwout + col] = -p.lr * c + wv;
+          } else if (row < p.M && col < p.N) {
+            epi_store<EPI>(p, row, col, epi_value<EPI>(p, acc[i][q][r], epi_aux<EPI>(p, row, col)), ks);
+          }
         }
+  } else {
+    // K split over the waves: wave wk finishes registers [wk*RS, (wk+1)*RS) of every accumulator.
+    // Every wave puts all its registers into LDS (the tile buffers are free now), sorted by owner;
+    // the owner adds the WK partial sums in the order of wk, so the result does not depend on
+    // timing.  Register numbers stay compile-time constants this way (only addresses depend on
+    // wk); selecting registers by wk made the compiler emit a 16-way select per element.
+    // Exchange image: [spatial wave][owner][source][accumulator][register][lane].
+    constexpr int RS = 16 / WK;
+    constexpr int NACC = TM * TN;
+    constexpr int XCH = WK * WK * NACC * RS * 64;  // floats per spatial wave position
+    static_assert(WAVES_M * WAVES_N * XCH <= 2 * (A_ELEMS + B_ELEMS), "exchange image larger than the tile buffers");
+    float *xch = lds + (wid % (WAVES_M * WAVES_N)) * XCH;
+    lds_barrier();  // every wave is done reading operand tiles
+#pragma unroll
+    for (int o = 0; o < WK; ++o)
+#pragma unroll
+      for (int a = 0; a < NACC; ++a)
+#pragma unroll
+        for (int rr = 0; rr < RS; ++rr)
+          xch[(((o * WK + wk) * NACC + a) * RS + rr) * 64 + lane] = acc[a / TN][a % TN][o * RS + rr];
+    float aux[NACC][RS];
+#pragma unroll
+    for (int a = 0; a < NACC; ++a)
+#pragma unroll
+      for (int rr = 0; rr < RS; ++rr) {
+        const int r = wk * RS + rr;
+        aux[a][rr] = epi_aux<EPI>(p, m0 + wm0 + (a / TN) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, n0 + wn0 + (a % TN) * 32 + li);
       }
+    lds_barrier();  // (not __syncthreads: the loads just issued stay in flight across it)
+    float sum[NACC][RS];
+#pragma unroll
+    for (int a = 0; a < NACC; ++a)
+#pragma unroll
+      for (int rr = 0; rr < RS; ++rr)
+#pragma unroll
+        for (int src = 0; src < WK; ++src) {
+          const float part = xch[(((wk * WK + src) * NACC + a) * RS + rr) * 64 + lane];
+          sum[a][rr] = (src == 0) ? part : sum[a][rr] + part;
+        }
+#pragma unroll
+    for (int a = 0; a < NACC; ++a)
+#pragma unroll
+      for (int rr = 0; rr < RS; ++rr) sum[a][rr] = epi_value<EPI>(p, sum[a][rr], aux[a][rr]);
+#pragma unroll
+    for (int a = 0; a < NACC; ++a)
+#pragma unroll
+      for (int rr = 0; rr < RS; ++rr) {
+        const int r = wk * RS + rr;
+        const int row = m0 + wm0 + (a / TN) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const int col = n0 + wn0 + (a % TN) * 32 + li;
+        if (row < p.M && col < p.N) epi_store<EPI>(p, row, col, sum[a][rr], ks);
+      }
+  }
   KH_STAMP(6);
 #ifdef KH_GEMM_STAMPS
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -636,7 +718,7 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(GemmParams p, const fl
     }
 #pragma unroll
     for (int i = 0; i < VEC; ++i)
-      if (c + i < p.N) epi_store<EPI>(p, r, c + i, acc[i], 0);
+      if (c + i < p.N) epi_store<EPI>(p, r, c + i, epi_value<EPI>(p, acc[i], epi_aux<EPI>(p, r, c + i)), 0);
   }
 }
 
@@ -644,12 +726,13 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(GemmParams p, const fl
 
 struct TileCfg {
   int bm, bn;
+  int wk;          // waves that split K inside the workgroup (1 = none)
   int lds_bytes;   // LDS per workgroup (K-major operands, the larger image)
   int vgprs;       // registers per lane, rounded
   double fixed;    // prologue + last tile + epilogue of a workgroup, cycles (measured with in-kernel stamps)
 };
-const TileCfg kCfgs[] = {{64, 64, 36864, 104, 4400.0}, {128, 64, 55296, 176, 5500.0}, {64, 128, 55296, 176, 5500.0},
-                         {128, 128, 73728, 208, 8300.0}};
+const TileCfg kCfgs[] = {{64, 64, 1, 36864, 104, 4400.0},  {128, 64, 1, 55296, 176, 5500.0}, {64, 128, 1, 55296, 176, 5500.0},
+                         {128, 128, 1, 73728, 208, 8300.0}, {32, 64, 2, 52224, 128, 4400.0},  {32, 32, 4, 67584, 128, 4400.0}};
 constexpr int kBK = 32;
 
 struct Plan {
@@ -671,20 +754,25 @@ struct Plan {
 int force_bm = -1, force_bn = -1, force_s = -1;
 bool env_read = false;
 
-Plan make_plan(int M, int N, int K, int num_cu, bool allow_split, bool always_slabs) {
+Plan make_plan(int M, int N, int K, int num_cu, bool allow_split, bool always_slabs, bool allow_wk) {
+  static bool wk_on = true;
   if (!env_read) {
     env_read = true;
     const char *e = getenv("KALDI_HIP_GEMM_FORCE");  // "BM,BN,S" for experiments
     if (e) sscanf(e, "%d,%d,%d", &force_bm, &force_bn, &force_s);
+    const char *w = getenv("KALDI_HIP_GEMM_WK");      // "0": never split K over the waves of a workgroup
+    if (w) wk_on = atoi(w) != 0;
   }
   Plan best = {0, 1, ((K + kBK - 1) / kBK) * kBK};
   double best_cost = 1e300;
   const int ncfg = (int)(sizeof(kCfgs) / sizeof(kCfgs[0]));
-  const int ktiles = (K + kBK - 1) / kBK;
   const double cyc_per_us = 2050.0;  // clock held under fp32 MFMA load
   for (int c = 0; c < ncfg; ++c) {
     const TileCfg &t = kCfgs[c];
-    if (force_bm > 0 ? (t.bm != force_bm || t.bn != force_bn) : (c != 0)) continue;
+    if (t.wk > 1 && !allow_wk) continue;
+    if (force_bm > 0 ? (t.bm != force_bm || t.bn != force_bn) : !(c == 0 || (t.wk > 1 && wk_on))) continue;
+    const int bkt = kBK * t.wk;
+    const int ktiles = (K + bkt - 1) / bkt;
     const int tm = (M + t.bm - 1) / t.bm, tn = (N + t.bn - 1) / t.bn;
     for (int s = 1; s <= 16; s *= 2) {
       if (s > 1 && !allow_split) break;
@@ -694,9 +782,10 @@ Plan make_plan(int M, int N, int K, int num_cu, bool allow_split, bool always_sl
       const int s_eff = (ktiles + kt_per - 1) / kt_per;
       if (s_eff != s) continue;
       const double blocks = (double)tm * tn * s;
-      const double kper = (double)kt_per * kBK;
+      const double kper = (double)kt_per * bkt;
       const double mfma = (double)t.bm * t.bn * kper * 2.0 / 256.0 * 1.08;
-      const double mem = (double)(t.bm + t.bn) * kper * 4.0 / 12.5;
+      // (K split over waves: same MFMA count per byte staged as the 64x64 tile is charged below)
+      const double mem = t.wk > 1 ? mfma * (1.28 / 1.08) : (double)(t.bm + t.bn) * kper * 4.0 / 12.5;
       const double per_block = mfma > mem ? mfma : mem;
       const double n = ceil(blocks / num_cu);
       // with two or more workgroups on every CU one's stalls are filled by another's MFMAs
@@ -708,29 +797,36 @@ Plan make_plan(int M, int N, int K, int num_cu, bool allow_split, bool always_sl
         best_cost = cost;
         best.cfg = c;
         best.splitk = s;
-        best.k_per_split = kt_per * kBK;
+        best.k_per_split = kt_per * bkt;
       }
     }
   }
   return best;
 }
 
-template <int BM, int BN, bool AK, bool BK_, int EPI>
+template <int BM, int BN, int WK, bool AK, bool BK_, int EPI>
 void launch_cfg(hipStream_t st, const GemmParams &p, bool vec) {
   const int nblk = p.tiles_m * p.tiles_n * p.splitk;
   if (vec)
-    hipLaunchKernelGGL((gemm_kernel<BM, BN, kBK, AK, BK_, EPI, true>), dim3(nblk), dim3(256), 0, st, p);
+    hipLaunchKernelGGL((gemm_kernel<BM, BN, kBK, WK, AK, BK_, EPI, true>), dim3(nblk), dim3(256), 0, st, p);
   else
-    hipLaunchKernelGGL((gemm_kernel<BM, BN, kBK, AK, BK_, EPI, false>), dim3(nblk), dim3(256), 0, st, p);
+    hipLaunchKernelGGL((gemm_kernel<BM, BN, kBK, WK, AK, BK_, EPI, false>), dim3(nblk), dim3(256), 0, st, p);
 }
 
 template <bool AK, bool BK_, int EPI>
 void launch_tiles(hipStream_t st, const GemmParams &p, int cfg, bool vec) {
+  constexpr bool kWaveK = (EPI != EPI_UPDATE && EPI != EPI_RBM);  // the planner never picks 4, 5 for those
   switch (cfg) {
-    case 0: launch_cfg<64, 64, AK, BK_, EPI>(st, p, vec); break;
-    case 1: launch_cfg<128, 64, AK, BK_, EPI>(st, p, vec); break;
-    case 2: launch_cfg<64, 128, AK, BK_, EPI>(st, p, vec); break;
-    default: launch_cfg<128, 128, AK, BK_, EPI>(st, p, vec); break;
+    case 0: launch_cfg<64, 64, 1, AK, BK_, EPI>(st, p, vec); break;
+    case 1: launch_cfg<128, 64, 1, AK, BK_, EPI>(st, p, vec); break;
+    case 2: launch_cfg<64, 128, 1, AK, BK_, EPI>(st, p, vec); break;
+    case 3: launch_cfg<128, 128, 1, AK, BK_, EPI>(st, p, vec); break;
+    case 4:
+      if constexpr (kWaveK) launch_cfg<32, 64, 2, AK, BK_, EPI>(st, p, vec);
+      break;
+    default:
+      if constexpr (kWaveK) launch_cfg<32, 32, 4, AK, BK_, EPI>(st, p, vec);
+      break;
   }
 }
 
@@ -805,7 +901,7 @@ int run_gemm(khStream_t s, bool a_kmajor, bool b_kmajor, GemmParams p, bool allo
   hipStream_t st = kh::pick(s);
   const bool vec = kh::aligned16(p.A) && kh::aligned16(p.B) && (p.lda % 4 == 0) && (p.ldb % 4 == 0);
   Plan plan = make_plan(p.M, p.N, p.K, kh::ctx().num_cu > 0 ? kh::ctx().num_cu : 256, allow_split || softmax,
-                        softmax);
+                        softmax, EPI != EPI_UPDATE && EPI != EPI_RBM);
   const int bm = kCfgs[plan.cfg].bm, bn = kCfgs[plan.cfg].bn;
   p.tiles_m = (p.M + bm - 1) / bm;
   p.tiles_n = (p.N + bn - 1) / bn;

@@ -396,6 +396,28 @@ def test_gemm_unaligned_and_exact(hip):
     assert (outs[0] == outs[1]).all() and (outs[0] == outs[2]).all()
 
 
+@pytest.mark.parametrize("bm,bn,s", [(64, 64, 1), (64, 64, 4), (128, 64, 2), (64, 128, 1), (128, 128, 2),
+                                     (32, 64, 1), (32, 64, 2), (32, 32, 1), (32, 32, 4)])
+def test_gemm_every_tile(hip, bm, bn, s):
+    """Every tile form of the kernel (the last four pairs split K over the waves of a workgroup), with and
+    without a split over workgroups, on ragged shapes in the three operand layouts of the path."""
+    h = hip
+    try:
+        h.call("hipK_gemm_force_plan", bm, bn, s)
+        for (M, N, K, ta, tb) in [(256, 2048, 1320, 0, 1), (256, 520, 1000, 0, 0), (130, 70, 200, 1, 0),
+                                  (33, 65, 64, 0, 1), (64, 96, 40, 0, 0)]:
+            A = rnd((K, M) if ta else (M, K), 36)
+            B = rnd((N, K) if tb else (K, N), 37)
+            C0 = rnd((M, N), 38)
+            dA, dB, dC = dev(h, A), dev(h, B), dev(h, C0)
+            h.call("hipF_gemm", None, h.TRANS if ta else h.NO_TRANS, h.TRANS if tb else h.NO_TRANS, M, N, K, f32(0.5),
+                   dA.ptr, dA.stride, dB.ptr, dB.stride, f32(1.0), dC.ptr, dC.stride)
+            ref = O.gemm(0.5, A, ta, B, tb, 1.0, C0)
+            np.testing.assert_allclose(dC.numpy(), ref, rtol=1e-5, atol=6e-6 * np.sqrt(K))
+    finally:
+        h.call("hipK_gemm_force_plan", 0, 0, 0)
+
+
 AFFINE_SHAPES = [(256, 1024, 440), (256, 1483, 1024), (256, 2048, 1320), (256, 2048, 2048), (256, 9000, 2048),
                  (16, 17, 24), (100, 33, 50)]
 

@@ -46,7 +46,9 @@ def main():
         }
         for name, fn in ops.items():
             res = []
-            for (bm, bn) in [(64, 64), (128, 64), (64, 128), (128, 128)]:
+            for (bm, bn) in [(64, 64), (128, 64), (64, 128), (128, 128), (32, 64), (32, 32)]:
+                if name.startswith("upd") and bm == 32:
+                    continue  # the update epilogue has no form with K split over waves
                 for s in ([1] if name.startswith("upd") else [1, 2, 4, 8]):
                     h.call("hipK_gemm_force_plan", bm, bn, s)
                     try:
@@ -58,7 +60,7 @@ def main():
             auto = bench(fn)
             res.sort()
             print("O=%5d I=%5d %s auto %6.1f us (%4.1f%%) | " % (O_, I, name, auto, fl / auto / PEAK * 1e8) +
-                  "  ".join("%dx%d/S%d %.1f" % (bm, bn, s, t) for t, bm, bn, s in res[:6]), flush=True)
+                  "  ".join("%dx%d/S%d %.1f" % (bm, bn, s, t) for t, bm, bn, s in res[:8]), flush=True)
 
 
 if __name__ == "__main__":
