@@ -18,6 +18,7 @@ struct Workspace {
   hipStream_t stream = nullptr;
   void *ptr = nullptr;
   size_t bytes = 0;
+  unsigned *ticket = nullptr;  // arrival counter of "last workgroup finishes the job" kernels; zero between launches
 };
 
 // Process-wide state: one GPU, one default stream, a scratch workspace per stream in use.
@@ -38,6 +39,8 @@ inline hipStream_t pick(khStream_t s) { return s ? (hipStream_t)s : ctx().stream
 
 // The workspace of stream `st`, grown to at least `bytes` (blocking when it has to reallocate).
 int ensure_workspace(hipStream_t st, size_t bytes, void **ptr);
+// The arrival counter of stream `st` (device memory, zero whenever no kernel that uses it is queued).
+int stream_ticket(hipStream_t st, unsigned **ticket);
 
 inline int launch_status() {
   hipError_t e = hipGetLastError();

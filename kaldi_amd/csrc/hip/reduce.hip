@@ -262,9 +262,57 @@ __global__ void diff_xent_kernel(const int32_t *tgt, float *mat, float *log_post
 }
 
 // ---- fused Xent::EvalVec -------------------------------------------------------------------
+// pass 2: counters and loss in a fixed order, by one workgroup
+__device__ __forceinline__ void xent_accum_block(const int32_t *tgt, const float *log_post, const int32_t *max_id,
+                                                 long long *counters, double *loss, int rows) {
+  __shared__ double sd[256];
+  __shared__ int sc[256];
+  double acc = 0.0;
+  int correct = 0;
+  for (int r = threadIdx.x; r < rows; r += 256) {
+    acc += (double)log_post[r];
+    correct += (max_id[r] == tgt[r]) ? 1 : 0;
+  }
+  sd[threadIdx.x] = acc;
+  sc[threadIdx.x] = correct;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) {
+      sd[threadIdx.x] += sd[threadIdx.x + o];
+      sc[threadIdx.x] += sc[threadIdx.x + o];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    counters[0] += sc[0];
+    counters[1] += rows;
+    loss[0] -= sd[0];
+  }
+}
+// Called by every workgroup of a one-row-per-workgroup kernel after thread 0 stored the row's
+// results: the workgroup that arrives last (a device-scope counter, back at zero afterwards) runs
+// pass 2, so no second kernel sits on the stream between the loss and the first backward GEMM.
+// The sums are taken in the same order whichever workgroup that is.
+struct XentTail {
+  unsigned *ticket;
+  long long *counters;
+  double *loss;
+};
+__device__ __forceinline__ void xent_finish(const XentTail &x, const int32_t *tgt, const float *log_post,
+                                            const int32_t *max_id, int rows) {
+  __shared__ unsigned arrived;
+  if (threadIdx.x == 0)
+    arrived = __hip_atomic_fetch_add(x.ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  if (arrived != gridDim.x - 1) return;
+  __atomic_thread_fence(__ATOMIC_ACQUIRE);  // every thread of this workgroup reads the other rows' results
+  xent_accum_block(tgt, log_post, max_id, x.counters, x.loss, rows);
+  if (threadIdx.x == 0) __hip_atomic_store(x.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // pass 1: one block per row: argmax, log posterior of the target, diff = post - onehot
 __global__ __launch_bounds__(256) void xent_rows_kernel(const float *post, const int32_t *tgt, float *diff,
-                                                        float *log_post, int32_t *max_id, MatrixDim d) {
+                                                        float *log_post, int32_t *max_id, MatrixDim d, XentTail tail) {
   __shared__ float sv[16];
   __shared__ int32_t si[16];
   const int r = blockIdx.x;
@@ -285,13 +333,15 @@ __global__ __launch_bounds__(256) void xent_rows_kernel(const float *post, const
     max_id[r] = b.i;
     log_post[r] = logf(pt < 1e-20f ? 1e-20f : pt);
   }
+  xent_finish(tail, tgt, log_post, max_id, d.rows);
 }
 // pass 1, fast form: the row is read once with 16-byte loads into registers (NV float4 per thread,
 // all loads in flight together), then argmax and diff come out of the registers.  Needs 16-byte
 // aligned rows, diff not aliasing post and cols <= 1024 * NV.
 template <int NV>
 __global__ __launch_bounds__(256) void xent_rows_vec_kernel(const float *post, const int32_t *tgt, float *diff,
-                                                            float *log_post, int32_t *max_id, MatrixDim d) {
+                                                            float *log_post, int32_t *max_id, MatrixDim d,
+                                                            XentTail tail) {
   __shared__ float sv[16];
   __shared__ int32_t si[16];
   const int r = blockIdx.x;
@@ -365,36 +415,8 @@ __global__ __launch_bounds__(256) void xent_rows_vec_kernel(const float *post, c
     const float ptv = t_ok ? ptot : 0.0f;
     log_post[r] = logf(ptv < 1e-20f ? 1e-20f : ptv);
   }
+  xent_finish(tail, tgt, log_post, max_id, d.rows);
 }
-// pass 2: one block: counters and loss in a fixed order
-__global__ __launch_bounds__(256) void xent_accum_kernel(const int32_t *tgt, const float *log_post,
-                                                         const int32_t *max_id, long long *counters, double *loss,
-                                                         int rows) {
-  __shared__ double sd[256];
-  __shared__ int sc[256];
-  double acc = 0.0;
-  int correct = 0;
-  for (int r = threadIdx.x; r < rows; r += 256) {
-    acc += (double)log_post[r];
-    correct += (max_id[r] == tgt[r]) ? 1 : 0;
-  }
-  sd[threadIdx.x] = acc;
-  sc[threadIdx.x] = correct;
-  __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) {
-    if (threadIdx.x < o) {
-      sd[threadIdx.x] += sd[threadIdx.x + o];
-      sc[threadIdx.x] += sc[threadIdx.x + o];
-    }
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) {
-    counters[0] += sc[0];
-    counters[1] += rows;
-    loss[0] -= sd[0];
-  }
-}
-
 // ---- fused Mse / MseProgress Eval ------------------------------------------------------------
 __global__ __launch_bounds__(256) void mse_rows_kernel(const float *a, const float *b, float *diff, float *row_sq,
                                                        MatrixDim d) {
@@ -524,16 +546,22 @@ KH_EXPORT int hipF_xent_eval(khStream_t s, const float *post, const int32_t *tgt
     if (!mi) mi = (int32_t *)((char *)ws + (size_t)d.rows * 4);
   }
   hipStream_t st = kh::pick(s);
+  XentTail tail;
+  tail.counters = counters;
+  tail.loss = loss;
+  {
+    int rc = kh::stream_ticket(st, &tail.ticket);
+    if (rc != KH_OK) return rc;
+  }
   const bool vec = (post != diff) && (d.stride % 4 == 0) && kh::aligned16(post) && kh::aligned16(diff);
   if (vec && d.cols <= 4096)
-    hipLaunchKernelGGL(xent_rows_vec_kernel<4>, dim3(d.rows), dim3(256), 0, st, post, tgt, diff, lp, mi, d);
+    hipLaunchKernelGGL(xent_rows_vec_kernel<4>, dim3(d.rows), dim3(256), 0, st, post, tgt, diff, lp, mi, d, tail);
   else if (vec && d.cols <= 10240)
-    hipLaunchKernelGGL(xent_rows_vec_kernel<10>, dim3(d.rows), dim3(256), 0, st, post, tgt, diff, lp, mi, d);
+    hipLaunchKernelGGL(xent_rows_vec_kernel<10>, dim3(d.rows), dim3(256), 0, st, post, tgt, diff, lp, mi, d, tail);
   else if (vec && d.cols <= 16384)
-    hipLaunchKernelGGL(xent_rows_vec_kernel<16>, dim3(d.rows), dim3(256), 0, st, post, tgt, diff, lp, mi, d);
+    hipLaunchKernelGGL(xent_rows_vec_kernel<16>, dim3(d.rows), dim3(256), 0, st, post, tgt, diff, lp, mi, d, tail);
   else
-    hipLaunchKernelGGL(xent_rows_kernel, dim3(d.rows), dim3(256), 0, st, post, tgt, diff, lp, mi, d);
-  hipLaunchKernelGGL(xent_accum_kernel, dim3(1), dim3(256), 0, st, tgt, lp, mi, counters, loss, d.rows);
+    hipLaunchKernelGGL(xent_rows_kernel, dim3(d.rows), dim3(256), 0, st, post, tgt, diff, lp, mi, d, tail);
   return kh::launch_status();
 }
 

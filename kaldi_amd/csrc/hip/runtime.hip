@@ -12,7 +12,7 @@ Context &ctx() {
   return c;
 }
 
-int ensure_workspace(hipStream_t st, size_t bytes, void **ptr) {
+static int workspace_of(hipStream_t st, Workspace **out) {
   Context &c = ctx();
   Workspace *w = nullptr;
   for (int i = 0; i < c.num_workspaces; ++i)
@@ -25,6 +25,26 @@ int ensure_workspace(hipStream_t st, size_t bytes, void **ptr) {
     w = &c.workspaces[c.num_workspaces++];
     w->stream = st;
   }
+  *out = w;
+  return KH_OK;
+}
+
+int stream_ticket(hipStream_t st, unsigned **ticket) {
+  Workspace *w;
+  int rc = workspace_of(st, &w);
+  if (rc != KH_OK) return rc;
+  if (!w->ticket) {
+    KH_HIP(hipMalloc((void **)&w->ticket, 256));
+    KH_HIP(hipMemset(w->ticket, 0, 256));
+  }
+  *ticket = w->ticket;
+  return KH_OK;
+}
+
+int ensure_workspace(hipStream_t st, size_t bytes, void **ptr) {
+  Workspace *w;
+  int rc = workspace_of(st, &w);
+  if (rc != KH_OK) return rc;
   if (bytes > w->bytes) {
     // Allocation churn is what this avoids: round up generously, reallocate rarely.
     size_t want = bytes + bytes / 4;
@@ -44,6 +64,7 @@ static int free_workspaces() {
   Context &c = ctx();
   for (int i = 0; i < c.num_workspaces; ++i) {
     if (c.workspaces[i].ptr) KH_HIP(hipFree(c.workspaces[i].ptr));
+    if (c.workspaces[i].ticket) KH_HIP(hipFree(c.workspaces[i].ticket));
     c.workspaces[i] = Workspace();
   }
   c.num_workspaces = 0;
@@ -164,6 +185,7 @@ KH_EXPORT int hipK_stream_destroy(khStream_t stream) {
   for (int i = 0; i < c.num_workspaces; ++i)
     if (c.workspaces[i].stream == (hipStream_t)stream) {
       if (c.workspaces[i].ptr) KH_HIP(hipFree(c.workspaces[i].ptr));
+      if (c.workspaces[i].ticket) KH_HIP(hipFree(c.workspaces[i].ticket));
       c.workspaces[i] = c.workspaces[--c.num_workspaces];
       c.workspaces[c.num_workspaces] = kh::Workspace();
       break;

@@ -9,10 +9,10 @@ rows = sorted(csv.DictReader(open(sys.argv[1])), key=lambda r: int(r["Start_Time
 
 def short(n):
     n = n.replace("(anonymous namespace)::", "").replace("void ", "")
-    m = re.match(r"gemm_kernel<(\d+), (\d+), (\d+), (\w+), (\w+), (\d), (\w+)>", n)
+    m = re.match(r"gemm_kernel<(\d+), (\d+), (\d+), (\d+), (\w+), (\w+), (\d), (\w+)>", n)
     if m:
-        lay = ("N" if m.group(4) == "true" else "T") + ("T" if m.group(5) == "true" else "N")
-        return "gemm %sx%sx%s %s epi%s" % (m.group(1), m.group(2), m.group(3), lay, m.group(6))
+        lay = ("N" if m.group(5) == "true" else "T") + ("T" if m.group(6) == "true" else "N")
+        return "gemm %sx%s wk%s %s epi%s" % (m.group(1), m.group(2), m.group(4), lay, m.group(7))
     return n.split("(")[0][:40]
 
 
