@@ -32,16 +32,31 @@ sys.path.insert(0, ROOT)
 
 F32_MFMA_PEAK_TFLOPS = 157.3   # MI355X dense fp32 matrix peak (256 CU x 4 SIMD x 64 FLOP/clk x 2.4 GHz)
 WORKLOADS = {
-    "swbd": dict(dims=[1320] + [2048] * 7 + [9000], name="swbd-1320-7x2048-9000-xent-train"),
-    "rm": dict(dims=[440, 1024, 1024, 1024, 1024, 1483], name="rm-440-4x1024-1483-xent-train"),
+    # kind "train": one bunch of nnet-train-xent-hardlab-frmshuff; "forward": one utterance of nnet-forward
+    # (Nnet::Feedforward, utterances of 300..1200 frames); "rbm": one bunch of rbm-train-cd1-frmshuff
+    "swbd": dict(kind="train", dims=[1320] + [2048] * 7 + [9000], name="swbd-1320-7x2048-9000-xent-train"),
+    "rm": dict(kind="train", dims=[440, 1024, 1024, 1024, 1024, 1483], name="rm-440-4x1024-1483-xent-train"),
+    "swbd-forward": dict(kind="forward", dims=[1320] + [2048] * 7 + [9000], name="swbd-1320-7x2048-9000-forward"),
+    "rm-forward": dict(kind="forward", dims=[440, 1024, 1024, 1024, 1024, 1483], name="rm-440-4x1024-1483-forward"),
+    "rbm-gauss-bern": dict(kind="rbm", dims=[440, 2048], types=("gauss", "bern"), lr=0.001, mom=0.5, l2=2e-4,
+                           name="rbm-440x2048-gauss-bern-cd1"),
+    "rbm-bern-bern": dict(kind="rbm", dims=[2048, 2048], types=("bern", "bern"), lr=0.1, mom=0.9, l2=2e-4,
+                          name="rbm-2048x2048-bern-bern-cd1"),
 }
+METRICS = {"train": "DNN train frames/sec (fwd+bwd+update)", "forward": "DNN forward frames/sec (nnet-forward)",
+           "rbm": "RBM CD-1 frames/sec"}
 BUNCH = 256
 
 
-def flops_per_frame(dims):
-    """2*MAC over the GEMMs of one training frame: forward 2P, weight gradient 2P, input gradient
-    2(P - P1) (the first layer's input gradient is never computed)."""
+def flops_per_frame(dims, kind="train"):
+    """2*MAC over the GEMMs of one frame.  Training: forward 2P, weight gradient 2P, input gradient
+    2(P - P1) (the first layer's input gradient is never computed).  Forward: 2P.  RBM CD-1: five
+    V x H products (three propagations / reconstructions, two statistics)."""
     p = [dims[i] * dims[i + 1] for i in range(len(dims) - 1)]
+    if kind == "forward":
+        return 2 * sum(p)
+    if kind == "rbm":
+        return 10 * p[0]
     return 6 * sum(p) - 2 * p[0]
 
 
@@ -62,6 +77,17 @@ def write_model(path, dims, seed):
             f.write(b"FV " + b"\x04" + np.int32(o).tobytes())
             f.write(b.tobytes())
             f.write(hdr(b"<softmax>" if last else b"<sigmoid>", o, o))
+
+
+def write_rbm(path, vis, hid, vis_type, hid_type, seed):
+    """random-init RBM in the nnet1 binary format (weights 0.1*N(0,1), biases 0: gen_rbm_init.py's scheme)"""
+    rs = np.random.RandomState(seed)
+    i32 = lambda v: b"\x04" + np.int32(v).tobytes()
+    with open(path, "wb") as f:
+        f.write(b"\0B<rbm> " + i32(hid) + i32(vis) + vis_type.encode() + b" " + hid_type.encode() + b" ")
+        f.write(b"FM " + i32(hid) + i32(vis) + (0.1 * rs.standard_normal((hid, vis))).astype("<f4").tobytes())
+        f.write(b"FV " + i32(vis) + np.zeros(vis, "<f4").tobytes())
+        f.write(b"FV " + i32(hid) + np.zeros(hid, "<f4").tobytes())
 
 
 def cpu_baseline(dims, model_path, tmp, frames=4096):
@@ -138,12 +164,16 @@ def main():
     h.init(local_rank)
 
     wl = WORKLOADS[args.workload]
-    dims = wl["dims"]
+    dims, kind = wl["dims"], wl["kind"]
     tmp = tempfile.mkdtemp(prefix="kaldi_amd_bench_")
     model_path = os.path.join(tmp, "model.nnet")
-    write_model(model_path, dims, seed=1)   # same weights on every rank, like a shared model-in file
+    # same weights on every rank, like a shared model-in file
+    if kind == "rbm":
+        write_rbm(model_path, dims[0], dims[1], wl["types"][0], wl["types"][1], seed=1)
+    else:
+        write_model(model_path, dims, seed=1)
 
-    if world > 1:
+    if world > 1 and kind == "train":
         # RCCL communicator of the device library: rank 0 creates the id, torch broadcasts the bytes
         uid = (ctypes.c_ubyte * h.COMM_ID_BYTES)()
         if rank == 0:
@@ -153,22 +183,41 @@ def main():
         uid = (ctypes.c_ubyte * h.COMM_ID_BYTES)(*t_uid.cpu().tolist())
         h.call("hipK_comm_init", uid, rank, world)
 
-    trainer = nn.Trainer(model_path)
-    trainer.set_train_opts(0.008)
-    if world > 1:
-        trainer.set_data_parallel(world)
-
-    # a synthetic, already shuffled frame cache resident in HBM (each rank its own frames)
-    cache_rows = 16 * BUNCH
     rs = np.random.RandomState(100 + rank)
-    cache = h.DevMatrix.from_numpy(rs.standard_normal((cache_rows, dims[0])).astype(np.float32))
-    labels = h.DevMatrix.from_numpy(rs.randint(0, dims[-1], cache_rows).astype(np.int32), pitched=False)
-    nb = cache_rows // BUNCH
+    if kind == "forward":
+        # utterance-sharded inference: every rank works through its own utterances, no collective
+        trainer = nn.Trainer(model_path)
+        lens = np.random.RandomState(777 + rank).randint(300, 1201, 16)
+        utts = [h.DevMatrix.from_numpy(rs.standard_normal((int(n), dims[0])).astype(np.float32)) for n in lens]
+        post = h.DevMatrix(int(lens.max()), dims[-1])
+        frames_of = lambda i: int(lens[i % len(utts)])
 
-    def step(i):
-        b = i % nb
-        trainer.train_bunch(ctypes.c_void_p(cache.ptr.value + b * BUNCH * cache.stride * 4), cache.stride, BUNCH,
-                            dims[0], ctypes.c_void_p(labels.ptr.value + b * BUNCH * 4))
+        def step(i):
+            trainer.feedforward(utts[i % len(utts)], post)
+    else:
+        if kind == "rbm":
+            trainer = nn.RbmTrainer(model_path)
+            trainer.set_train_opts(wl["lr"], wl["mom"], wl["l2"])
+        else:
+            trainer = nn.Trainer(model_path)
+            trainer.set_train_opts(0.008)
+            if world > 1:
+                trainer.set_data_parallel(world)
+        # a synthetic, already shuffled frame cache resident in HBM (each rank its own frames)
+        cache_rows = 16 * BUNCH
+        x = rs.standard_normal((cache_rows, dims[0])) if wl.get("types", ("gauss",))[0] == "gauss" else rs.random_sample((cache_rows, dims[0]))
+        cache = h.DevMatrix.from_numpy(x.astype(np.float32))
+        labels = h.DevMatrix.from_numpy(rs.randint(0, dims[-1], cache_rows).astype(np.int32), pitched=False)
+        nb = cache_rows // BUNCH
+        frames_of = lambda i: BUNCH
+
+        def step(i):
+            b = i % nb
+            rows = ctypes.c_void_p(cache.ptr.value + b * BUNCH * cache.stride * 4)
+            if kind == "rbm":
+                trainer.cd1_bunch(rows, cache.stride, BUNCH, dims[0])
+            else:
+                trainer.train_bunch(rows, cache.stride, BUNCH, dims[0], ctypes.c_void_p(labels.ptr.value + b * BUNCH * 4))
 
     def fence():
         nn.synchronize()
@@ -191,8 +240,9 @@ def main():
         dist.all_reduce(t_el, op=dist.ReduceOp.MAX)
         elapsed = float(t_el.item())
 
-    frames, correct, loss = trainer.stats()
-    value = world * BUNCH * args.steps / elapsed
+    frames, correct, loss = trainer.stats() if kind == "train" else (0, 0, 0.0)
+    done = sum(frames_of(i) for i in range(args.steps))  # frames of this rank inside the timed region
+    value = world * done / elapsed
 
     # Roofline of the dominant kernel: the same steps once more with every GEMM launch bracketed by
     # HIP events on the stream it is queued on (a pass of its own: the event markers would
@@ -211,7 +261,7 @@ def main():
     fence()
 
     if rank == 0:
-        fpf = flops_per_frame(dims)
+        fpf = flops_per_frame(dims, kind)
         # achieved = algorithmic FLOPs / time the GEMM kernels occupy the chip (overlapping launches
         # counted once); per_launch = the same FLOPs / summed launch durations
         achieved = fl.value / (busy.value * 1e-3) / 1e12 if busy.value > 0 else 0.0
@@ -223,12 +273,15 @@ def main():
         if args.workload == "swbd" and os.path.exists(tf):
             traffic = json.load(open(tf)).get("gemm_hbm_bytes_per_launch")
         out = {
-            "metric": "DNN train frames/sec (fwd+bwd+update), %s" % args.workload,
+            "metric": "%s, %s" % (METRICS[kind], args.workload),
             "value": round(value, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": wl["name"], "bunch_per_gpu": BUNCH, "global_bunch": BUNCH * world,
-                       "parallelism": "dp%d" % world if world > 1 else "single", "flops_per_frame": fpf,
+            "config": {"workload": wl["name"], "bunch_per_gpu": BUNCH if kind != "forward" else None,
+                       "global_bunch": BUNCH * world if kind != "forward" else None,
+                       "frames_per_step": round(done / args.steps, 1),
+                       "parallelism": ("single" if world == 1 else "dp%d" % world if kind == "train" else "replicas%d" % world),
+                       "flops_per_frame": fpf,
                        "pct_fp32_mfma_peak_end_to_end": round(100.0 * value * fpf / world / (F32_MFMA_PEAK_TFLOPS * 1e12), 2)},
             "roofline": {"bound": "mfma", "kernel": "gemm_kernel (fp32 v_mfma_f32_32x32x2_f32, all layouts)",
                          "achieved": round(achieved, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -242,13 +295,14 @@ def main():
                          "instrumented_pass_ms_per_step": round(roof_wall / roof_steps * 1e3, 4)},
             "check": {"frames": frames, "mean_xent": round(loss / max(frames, 1), 4)},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and kind == "train":
             out["cpu_baseline"] = cpu_baseline(dims, model_path, tmp)
         print(json.dumps(out), flush=True)
 
     trainer.close()
-    if world > 1:
+    if world > 1 and kind == "train":
         h.call("hipK_comm_destroy")
+    if world > 1:
         dist.barrier()
         dist.destroy_process_group()
     for f in os.listdir(tmp):
