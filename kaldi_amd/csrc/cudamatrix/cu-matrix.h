@@ -40,15 +40,18 @@ class CuMatrix {
   typedef CuMatrix<Real> ThisType;
 
  public:
-  CuMatrix() : num_rows_(0), num_cols_(0), stride_(0), data_(NULL), owner_(true) {}
-  CuMatrix(MatrixIndexT rows, MatrixIndexT cols) : num_rows_(0), num_cols_(0), stride_(0), data_(NULL), owner_(true) {
+  CuMatrix() : num_rows_(0), num_cols_(0), stride_(0), data_(NULL), owner_(true), capacity_(0) {}
+  CuMatrix(MatrixIndexT rows, MatrixIndexT cols)
+      : num_rows_(0), num_cols_(0), stride_(0), data_(NULL), owner_(true), capacity_(0) {
     Resize(rows, cols);
   }
   CuMatrix(ThisType &&o) noexcept
-      : num_rows_(o.num_rows_), num_cols_(o.num_cols_), stride_(o.stride_), data_(o.data_), owner_(o.owner_) {
+      : num_rows_(o.num_rows_), num_cols_(o.num_cols_), stride_(o.stride_), data_(o.data_), owner_(o.owner_),
+        capacity_(o.capacity_) {
     o.num_rows_ = o.num_cols_ = o.stride_ = 0;
     o.data_ = NULL;
     o.owner_ = true;
+    o.capacity_ = 0;
   }
   ThisType &operator=(ThisType &&o) noexcept {
     if (this != &o) {
@@ -80,20 +83,32 @@ class CuMatrix {
   MatrixIndexT RowSizeInBytes() const { return num_cols_ * sizeof(Real); }
   MatrixIndexT StrideSizeInBytes() const { return stride_ * sizeof(Real); }
 
-  /// No-op when the shape is unchanged; otherwise frees, allocates (rows start 256-byte aligned)
-  /// and zero-fills, padding included.
+  /// No-op when the shape is unchanged; otherwise the matrix gets the new shape (rows start
+  /// 256-byte aligned) and is zero-filled, padding included.  An allocation that is large enough is
+  /// kept (per-utterance buffers change shape all the time; cudaMalloc/cudaFree per Resize, as in
+  /// cu-matrix-inl.h:96-130, would synchronise the device each time).
   ThisType &Resize(MatrixIndexT rows, MatrixIndexT cols) {
     if (owner_ && num_rows_ == rows && num_cols_ == cols) return *this;  // a view always lets go
     KALDI_ASSERT(rows >= 0 && cols >= 0);
+    const size_t pitch = (static_cast<size_t>(cols) * sizeof(Real) + 255) & ~static_cast<size_t>(255);
+    if (owner_ && data_ && rows > 0 && cols > 0 && pitch * rows <= capacity_) {
+      num_rows_ = rows;
+      num_cols_ = cols;
+      stride_ = static_cast<MatrixIndexT>(pitch / sizeof(Real));
+      SetZero();
+      return *this;
+    }
     Destroy();
     if (rows == 0 || cols == 0) return *this;
     void *p = NULL;
     int32_t stride = 0;
     CU_SAFE_CALL(hipK_malloc_pitch(&p, &stride, rows, cols, sizeof(Real)));
+    KALDI_ASSERT(static_cast<size_t>(stride) * sizeof(Real) == pitch);
     data_ = static_cast<Real *>(p);
     num_rows_ = rows;
     num_cols_ = cols;
     stride_ = stride;
+    capacity_ = pitch * rows;
     SetZero();
     return *this;
   }
@@ -105,6 +120,7 @@ class CuMatrix {
     }
     data_ = NULL;
     owner_ = true;
+    capacity_ = 0;
     num_rows_ = num_cols_ = stride_ = 0;
   }
   /// Makes this matrix a non-owning window onto rows [row0, row0+rows) of `src` (no copy; not in the
@@ -128,6 +144,7 @@ class CuMatrix {
   bool IsView() const { return !owner_; }
   void Swap(ThisType *o) {
     std::swap(owner_, o->owner_);
+    std::swap(capacity_, o->capacity_);
     std::swap(num_rows_, o->num_rows_);
     std::swap(num_cols_, o->num_cols_);
     std::swap(stride_, o->stride_);
@@ -256,6 +273,7 @@ class CuMatrix {
   MatrixIndexT num_rows_, num_cols_, stride_;
   Real *data_;
   bool owner_;  // false: a window onto memory owned elsewhere (AttachView)
+  size_t capacity_;  // bytes of the allocation this matrix owns (>= rows * stride)
   CuMatrix(const ThisType &) = delete;
   ThisType &operator=(const ThisType &) = delete;
 };

@@ -15,6 +15,7 @@ import bench  # noqa: E402  (model writer and the layer sizes)
 
 which = sys.argv[1] if len(sys.argv) > 1 else "swbd"
 frames = int(sys.argv[2]) if len(sys.argv) > 2 else 200000
+extra = sys.argv[3:]  # further options for both tools, e.g. --profile=true
 dims = bench.WORKLOADS[which]["dims"]
 tmp = tempfile.mkdtemp(prefix="tool_fps_", dir="/tmp")
 rs = np.random.RandomState(777)
@@ -47,17 +48,17 @@ def run(cmd):
         print(err[-2000:])
         sys.exit(1)
     for line in err.splitlines():
-        if "fps" in line or "FRAME_ACCURACY" in line or "time" in line.lower():
+        if extra or "fps" in line or "FRAME_ACCURACY" in line or "time" in line.lower():
             print("   ", line.strip())
     print("    wall %.2f s -> %.0f frames/s including start-up" % (wall, n / wall), flush=True)
 
 
 bindir = os.path.join(ROOT, "kaldi_amd", "bin")
 print("nnet-train-xent-hardlab-frmshuff:")
-run([os.path.join(bindir, "nnet-train-xent-hardlab-frmshuff"), "--learn-rate=0.008", "--binary=true", "ark:" + feats,
+run([os.path.join(bindir, "nnet-train-xent-hardlab-frmshuff"), "--learn-rate=0.008", "--binary=true"] + extra + ["ark:" + feats,
      "ark:" + ali, model, os.path.join(tmp, "out.nnet")])
 print("nnet-forward:")
-run([os.path.join(bindir, "nnet-forward"), model, "ark:" + feats, "ark:" + os.path.join(tmp, "post.ark")])
+run([os.path.join(bindir, "nnet-forward")] + extra + [model, "ark:" + feats, "ark:" + os.path.join(tmp, "post.ark")])
 for f in os.listdir(tmp):
     os.remove(os.path.join(tmp, f))
 os.rmdir(tmp)
