@@ -70,7 +70,7 @@ int main(int argc, char *argv[]) {
     nnet_transf.SetFusion(fused);
 
     kaldi::int64 tot_t = 0;
-    SequentialBaseFloatMatrixReader feature_reader(feature_rspecifier);
+    PrefetchingBaseFloatMatrixReader feature_reader(feature_rspecifier);  // reads ahead on a thread of its own
     BaseFloatMatrixWriter feature_writer(feature_wspecifier);
 
     CuMatrix<BaseFloat> feats, feats_transf, nnet_out;

@@ -88,7 +88,7 @@ int main(int argc, char *argv[]) {
 
     kaldi::int64 tot_t = 0;
 
-    SequentialBaseFloatMatrixReader feature_reader(feature_rspecifier);
+    PrefetchingBaseFloatMatrixReader feature_reader(feature_rspecifier);  // reads ahead on a thread of its own
     RandomAccessInt32VectorReader alignments_reader(alignments_rspecifier);
 
     Cache cache;

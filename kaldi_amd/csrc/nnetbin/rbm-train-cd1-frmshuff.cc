@@ -60,7 +60,7 @@ int main(int argc, char *argv[]) {
     rbm.SetL2Penalty(l2_penalty);
 
     kaldi::int64 tot_t = 0;
-    SequentialBaseFloatMatrixReader feature_reader(feature_rspecifier);
+    PrefetchingBaseFloatMatrixReader feature_reader(feature_rspecifier);  // reads ahead on a thread of its own
 
     Cache cache;
     cachesize = (cachesize / bunchsize) * bunchsize;

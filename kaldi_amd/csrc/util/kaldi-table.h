@@ -5,7 +5,12 @@
 // Archive layout: for each entry  "<key> " + holder payload.  Script layout: "<key> <xfilename>\n".
 #ifndef KALDI_AMD_UTIL_KALDI_TABLE_H_
 #define KALDI_AMD_UTIL_KALDI_TABLE_H_
+#include <condition_variable>
+#include <deque>
+#include <exception>
 #include <memory>
+#include <mutex>
+#include <thread>
 #include <string>
 #include <unordered_map>
 #include <utility>
@@ -129,6 +134,97 @@ class SequentialTableReader {
   bool done_;
   std::vector<std::pair<std::string, std::string> > script_;
   size_t pos_;
+};
+
+// ---- sequential reader with a read-ahead thread ---------------------------------------------
+// Same interface as SequentialTableReader; a background thread reads and parses entries ahead of
+// the consumer into a bounded queue, so that file / pipe input overlaps the consumer's work (the
+// training tools spend their time waiting for the GPU, not for the table: "feature wait",
+// nnetbin/nnet-train-xent-hardlab-frmshuff.cc:153-155).  Errors raised while reading are handed to
+// the consumer at the entry where they occurred.  Not in the reference.
+template <class Holder>
+class PrefetchingTableReader {
+ public:
+  typedef typename Holder::T T;
+  explicit PrefetchingTableReader(const std::string &rspecifier, size_t max_ahead = 64)
+      : reader_(rspecifier), max_ahead_(max_ahead), stop_(false), finished_(false), have_(false) {
+    thread_ = std::thread(&PrefetchingTableReader::Run, this);
+    Pop();
+  }
+  ~PrefetchingTableReader() {
+    {
+      std::lock_guard<std::mutex> l(mu_);
+      stop_ = true;
+    }
+    cv_space_.notify_all();
+    if (thread_.joinable()) thread_.join();
+  }
+  bool Done() const { return !have_; }
+  std::string Key() const {
+    if (!have_) KALDI_ERR << "TableReader: Key() called when Done()";
+    return cur_->key;
+  }
+  const T &Value() {
+    if (!have_) KALDI_ERR << "TableReader: Value() called when Done()";
+    return cur_->value;
+  }
+  void Next() {
+    if (!have_) KALDI_ERR << "TableReader: Next() called when Done()";
+    Pop();
+  }
+
+ private:
+  struct Item {
+    std::string key;
+    T value;
+  };
+  void Run() {
+    try {
+      for (; !reader_.Done(); reader_.Next()) {
+        std::unique_ptr<Item> it(new Item);
+        it->key = reader_.Key();
+        it->value = reader_.Value();
+        std::unique_lock<std::mutex> l(mu_);
+        cv_space_.wait(l, [this] { return stop_ || queue_.size() < max_ahead_; });
+        if (stop_) return;
+        queue_.push_back(std::move(it));
+        cv_item_.notify_one();
+      }
+    } catch (...) {
+      std::lock_guard<std::mutex> l(mu_);
+      error_ = std::current_exception();
+    }
+    std::lock_guard<std::mutex> l(mu_);
+    finished_ = true;
+    cv_item_.notify_all();
+  }
+  void Pop() {
+    std::unique_lock<std::mutex> l(mu_);
+    cv_item_.wait(l, [this] { return !queue_.empty() || finished_; });
+    if (!queue_.empty()) {
+      cur_ = std::move(queue_.front());
+      queue_.pop_front();
+      have_ = true;
+      cv_space_.notify_one();
+      return;
+    }
+    have_ = false;
+    cur_.reset();
+    if (error_) {
+      std::exception_ptr e = error_;
+      error_ = nullptr;
+      std::rethrow_exception(e);
+    }
+  }
+  SequentialTableReader<Holder> reader_;
+  size_t max_ahead_;
+  std::thread thread_;
+  std::mutex mu_;
+  std::condition_variable cv_item_, cv_space_;
+  std::deque<std::unique_ptr<Item> > queue_;
+  std::unique_ptr<Item> cur_;
+  std::exception_ptr error_;
+  bool stop_, finished_, have_;
 };
 
 // ---- random-access reader ------------------------------------------------------------------
