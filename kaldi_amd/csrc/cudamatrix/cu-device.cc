@@ -23,6 +23,7 @@ void CuDevice::SelectGpuId(int32 gpu_id) {
   stream_ = main_stream_;
   side_stream_ = NULL;
   aux_stream_ = NULL;
+  copy_stream_ = NULL;
   initialised_ = true;
   if (verbose_) {
     char arch[64];

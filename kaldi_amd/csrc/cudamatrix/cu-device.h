@@ -62,6 +62,22 @@ class CuDevice {
     if (aux_stream_ == NULL) CU_SAFE_CALL(hipK_stream_create(&aux_stream_));
     return aux_stream_;
   }
+  /// A stream for host-to-device uploads that should run beside the training kernels (the tools'
+  /// feature uploads); same rules as the side stream.
+  khStream_t CopyStream() {
+    EnsureInit();
+    if (copy_stream_ == NULL) {
+      // Created after the other two, whatever the order of first use.  The runtime maps streams onto a few
+      // hardware queues in creation order; the main, side and update streams wait for each other through
+      // events and must not end up behind one another in one queue (created first, the copy stream
+      // shifted them so that a training step never finished).  This one only carries copies the host
+      // waits for, so it may share a queue with any of them.
+      SideStream();
+      AuxStream();
+      CU_SAFE_CALL(hipK_stream_create(&copy_stream_));
+    }
+    return copy_stream_;
+  }
   /// `waiter` continues only after everything queued on `done` so far has finished (no host wait).
   void Order(khStream_t done, khStream_t waiter, khEvent_t *ev) {
     if (*ev == NULL) CU_SAFE_CALL(hipK_event_create(ev));
@@ -80,12 +96,12 @@ class CuDevice {
   friend class CuStreamScope;
   CuDevice()
       : initialised_(false), requested_gpu_id_(-1), active_gpu_id_(-1), verbose_(true), profiling_(false),
-        stream_(NULL), main_stream_(NULL), side_stream_(NULL), aux_stream_(NULL) {}
+        stream_(NULL), main_stream_(NULL), side_stream_(NULL), aux_stream_(NULL), copy_stream_(NULL) {}
   ~CuDevice() {}
   bool initialised_;
   int32 requested_gpu_id_, active_gpu_id_;
   bool verbose_, profiling_;
-  khStream_t stream_, main_stream_, side_stream_, aux_stream_;
+  khStream_t stream_, main_stream_, side_stream_, aux_stream_, copy_stream_;
   std::map<std::string, double> profile_map_;
   KALDI_DISALLOW_COPY_AND_ASSIGN(CuDevice);
 };

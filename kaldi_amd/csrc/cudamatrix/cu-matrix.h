@@ -184,6 +184,14 @@ class CuMatrix {
            src.stride_, num_cols_, r, 2);
   }
 
+  /// rows [src_ro, src_ro + r) of a host matrix into rows [dst_ro, ...) of this one (blocking; not in the reference)
+  void CopyRowsFromMat(int32 r, const Matrix<Real> &src, int32 src_ro, int32 dst_ro) {
+    KALDI_ASSERT(r >= 0 && r + src_ro <= src.NumRows() && r + dst_ro <= NumRows() && src_ro >= 0 && dst_ro >= 0);
+    KALDI_ASSERT(src.NumCols() == NumCols());
+    if (r == 0) return;
+    Copy2D(data_ + static_cast<size_t>(dst_ro) * stride_, stride_, src.RowData(src_ro), src.Stride(), num_cols_, r, 0);
+  }
+
   void Read(std::istream &is, bool binary) {
     Matrix<Real> tmp;
     tmp.Read(is, binary);

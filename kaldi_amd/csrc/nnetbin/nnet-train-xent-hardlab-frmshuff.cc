@@ -9,6 +9,7 @@
 #include "nnet/nnet-loss.h"
 #include "nnet/nnet-nnet.h"
 #include "nnetbin/dist-utils.h"
+#include "nnetbin/feature-upload.h"
 #include "util/common-utils.h"
 #include "util/timer.h"
 
@@ -97,7 +98,8 @@ int main(int argc, char *argv[]) {
 
     Xent xent;
 
-    CuMatrix<BaseFloat> feats, feats_transf, nnet_in, nnet_out, glob_err;
+    CuMatrix<BaseFloat> feats_transf, nnet_in, nnet_out, glob_err;
+    FeatureUploader uploader(cachesize);
     CuStlVector<int32> targets;
     ShardAssigner shard(dist.num_ranks);
 
@@ -124,7 +126,7 @@ int main(int argc, char *argv[]) {
               if (alignment[i] < 0 || alignment[i] >= nnet.OutputDim())
                 KALDI_ERR << "Alignment of " << key << " has label " << alignment[i] << " outside the network's "
                           << nnet.OutputDim() << " outputs";
-            feats.CopyFromMat(mat);                            // host -> device
+            const CuMatrix<BaseFloat> &feats = uploader.Upload(mat);  // host -> device, beside the training
             nnet_transf.Feedforward(feats, &feats_transf);     // optional transform
             cache.AddData(feats_transf, alignment);
             num_done++;

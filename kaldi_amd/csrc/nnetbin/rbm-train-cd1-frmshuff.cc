@@ -5,6 +5,7 @@
 #include "cudamatrix/cu-device.h"
 #include "cudamatrix/cu-rand.h"
 #include "nnet/nnet-cache.h"
+#include "nnetbin/feature-upload.h"
 #include "nnet/nnet-loss.h"
 #include "nnet/nnet-nnet.h"
 #include "nnet/nnet-rbm.h"
@@ -69,7 +70,8 @@ int main(int argc, char *argv[]) {
     CuRand<BaseFloat> cu_rand;
     MseProgress mse;
 
-    CuMatrix<BaseFloat> feats, feats_transf, pos_vis, pos_hid, neg_vis, neg_hid, dummy_mse_mat;
+    FeatureUploader uploader(cachesize);
+    CuMatrix<BaseFloat> feats_transf, pos_vis, pos_hid, neg_vis, neg_hid, dummy_mse_mat;
     std::vector<int32> dummy_cache_vec;
     CuStlVector<int32> dummy_targets;
 
@@ -82,7 +84,7 @@ int main(int argc, char *argv[]) {
       while (!cache.Full() && !feature_reader.Done()) {
         const Matrix<BaseFloat> &mat = feature_reader.Value();
         dummy_cache_vec.resize(mat.NumRows());  // the cache wants labels; RBM training has none
-        feats.CopyFromMat(mat);
+        const CuMatrix<BaseFloat> &feats = uploader.Upload(mat);  // host -> device, beside the training
         rbm_transf.Feedforward(feats, &feats_transf);
         cache.AddData(feats_transf, dummy_cache_vec);
         num_done++;
