@@ -59,5 +59,33 @@ class Cache {
   CuStlVector<int32> randmask_device_;
 };
 
+// The same cache with a matrix of regression targets per utterance instead of labels
+// (nnet/nnet-cache-tgtmat.h:30-97, nnet-cache-tgtmat.cc:28-200): features and targets are
+// appended, carried over and permuted together.
+class CacheTgtMat {
+  typedef enum { EMPTY, FILLING, FULL, EMPTYING } State;
+
+ public:
+  CacheTgtMat() : state_(EMPTY), filling_pos_(0), emptying_pos_(0), cachesize_(0), bunchsize_(0), randomized_(false) {}
+  void Init(int32 cachesize, int32 bunchsize);
+  void AddData(const CuMatrix<BaseFloat> &features, const CuMatrix<BaseFloat> &targets);
+  void Randomize();
+  void Randomize(const std::vector<int32> &randmask);
+  void GetBunch(CuMatrix<BaseFloat> *features, CuMatrix<BaseFloat> *targets);
+  bool Full() { return state_ == FULL; }
+  bool Empty() { return state_ == EMPTY || filling_pos_ < bunchsize_; }
+  bool Randomized() { return randomized_; }
+
+ private:
+  State state_;
+  size_t filling_pos_, emptying_pos_;
+  size_t cachesize_, bunchsize_;
+  bool randomized_;
+  CuMatrix<BaseFloat> features_, features_random_, features_leftover_;
+  CuMatrix<BaseFloat> targets_, targets_random_, targets_leftover_;
+  std::vector<int32> randmask_;
+  CuStlVector<int32> randmask_device_;
+};
+
 }  // namespace kaldi
 #endif

@@ -527,6 +527,24 @@ class Rbm:
         self.hid_bias = (self.hid_bias_corr + self.hid_bias).astype(f32)
 
 
+def rbm_as_nnet(rbm):
+    """Rbm::WriteAsNnet, nnet/nnet-rbm.h:233-249: the hidden side as <biasedlinearity>, followed by
+    <sigmoid> when the hidden units are Bernoulli."""
+    layers = [BiasedLinearity(rbm.W.copy(), rbm.hid_bias.copy())]
+    if rbm.hid_type == "bern":
+        layers.append(Sigmoid(rbm.W.shape[0]))
+    return layers
+
+
+def write_rbm_as_nnet(rbm, binary):
+    """rbm-convert-to-nnet's output file: in text mode WriteAsNnet ends with a newline of its own,
+    which follows the bias vector's when there is no <sigmoid> line (nnet-rbm.h:247)."""
+    out = write_nnet(rbm_as_nnet(rbm), binary)
+    if not binary and rbm.hid_type != "bern":
+        out += b"\n"
+    return out
+
+
 def binarize_probs(probs, uniform):
     """cudamatrix/cu-randkernels.cu:113-120 / cu-rand-inl.h:163-167 with the uniform draws injected:
     state = probs > rand ? 1 : 0."""

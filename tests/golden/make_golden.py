@@ -268,6 +268,69 @@ def gen_rm_shape(tmp):
     print("rm_shape_step: %d arrays" % len(fix))
 
 
+def gen_siblings(tmp):
+    """The sibling tools that share the trainer's kernels: per-utterance cross-entropy training,
+    frame-shuffled MSE training on target matrices (shuffled and cross-validation runs), nnet-copy in both
+    directions, rbm-convert-to-nnet."""
+    rs = np.random.RandomState(4242)
+    dims = [24, 32, 32, 17]
+    layers = make_dnn(rs, dims)
+    lengths = [30, 5, 40, 17, 1, 38, 33, 21, 29]
+    utts = [("spk%02d" % i, rs.randn(n, dims[0]).astype(f32)) for i, n in enumerate(lengths)]
+    alis = [(k, rs.randint(0, dims[-1], m.shape[0]).astype(np.int32)) for k, m in utts]
+    model = O.write_nnet(layers, True)
+    P = lambda n: os.path.join(tmp, n)
+    open(P("sm.bin"), "wb").write(model)
+    open(P("sf.ark"), "wb").write(O.write_matrix_ark(utts))
+    open(P("sa.ark"), "wb").write(O.write_int32_vector_ark(alis, binary=False))
+    fix = {"model": np.frombuffer(model, np.uint8), "feats_ark": np.frombuffer(O.write_matrix_ark(utts), np.uint8),
+           "ali_ark_txt": np.frombuffer(O.write_int32_vector_ark(alis, binary=False), np.uint8)}
+    # per-utterance trainer
+    for name, opts in {"perutt": [], "perutt_mom": ["--momentum=0.5", "--learn-rate=0.02"]}.items():
+        _, err = run([os.path.join(BIN, "nnet-train-xent-hardlab-perutt"), "--binary=true"] + opts +
+                     ["ark:" + P("sf.ark"), "ark:" + P("sa.ark"), P("sm.bin"), P("so.nnet")])
+        m = re.search(r"Xent:(\S+) frames:(\d+) err/frm:(\S+)\s*\nFRAME_ACCURACY >> (\S+)% <<", err)
+        fix[name + "_xent"], fix[name + "_frames"] = np.float64(m.group(1)), np.int64(m.group(2))
+        fix[name + "_report"] = np.frombuffer(m.group(0).encode(), np.uint8)
+        fix[name + "_model_out"] = np.frombuffer(open(P("so.nnet"), "rb").read(), np.uint8)
+    # MSE trainer: 24 -> 32 sigmoid -> 24 linear, targets = noisy copies of the input
+    ae = make_dnn(rs, [24, 32, 24], softmax=False)
+    ae_model = O.write_nnet(ae, True)
+    tgts = [(k, (m + 0.1 * rs.randn(*m.shape)).astype(f32)) for k, m in utts]
+    open(P("am.bin"), "wb").write(ae_model)
+    open(P("at.ark"), "wb").write(O.write_matrix_ark(tgts))
+    fix["ae_model"] = np.frombuffer(ae_model, np.uint8)
+    fix["tgt_ark"] = np.frombuffer(O.write_matrix_ark(tgts), np.uint8)
+    for name, opts in {"mse": [], "mse_cv": ["--cross-validate=true"],
+                       "mse_mom": ["--momentum=0.9", "--learn-rate=0.05", "--average-grad=true"]}.items():
+        args = [os.path.join(BIN, "nnet-train-mse-tgtmat-frmshuff"), "--bunchsize=16", "--cachesize=64", "--binary=true"] + opts + [
+            "ark:" + P("sf.ark"), "ark:" + P("at.ark"), P("am.bin")]
+        if name != "mse_cv":
+            args.append(P("ao.nnet"))
+        _, err = run(args)
+        m = re.search(r"Mse:(\S+) frames:(\d+) err/frm:(\S+)", err)
+        fix[name + "_loss"], fix[name + "_frames"] = np.float64(m.group(1)), np.int64(m.group(2))
+        fix[name + "_cache_lines"] = np.frombuffer("\n".join(re.findall(r"Cache #.*", err)).encode(), np.uint8)
+        if name != "mse_cv":
+            fix[name + "_model_out"] = np.frombuffer(open(P("ao.nnet"), "rb").read(), np.uint8)
+    # nnet-copy both ways
+    run([os.path.join(BIN, "nnet-copy"), "--binary=false", P("sm.bin"), P("sm.txt")])
+    run([os.path.join(BIN, "nnet-copy"), "--binary=true", P("sm.txt"), P("sm2.bin")])
+    fix["copy_txt"] = np.frombuffer(open(P("sm.txt"), "rb").read(), np.uint8)
+    fix["copy_bin"] = np.frombuffer(open(P("sm2.bin"), "rb").read(), np.uint8)
+    # rbm-convert-to-nnet for both hidden unit types
+    for name, (vt, ht) in {"bb": ("bern", "bern"), "gb": ("gauss", "bern"), "bg": ("bern", "gauss")}.items():
+        rbm = O.Rbm((0.1 * rs.randn(32, 24)).astype(f32), (0.1 * rs.randn(24)).astype(f32), (0.1 * rs.randn(32)).astype(f32), vt, ht)
+        open(P("r.rbm"), "wb").write(O.write_nnet([rbm], True))
+        run([os.path.join(BIN, "rbm-convert-to-nnet"), "--binary=true", P("r.rbm"), P("r.nnet")])
+        run([os.path.join(BIN, "rbm-convert-to-nnet"), P("r.rbm"), P("r.txt")])
+        fix["rbm_" + name] = np.frombuffer(O.write_nnet([rbm], True), np.uint8)
+        fix["rbm_%s_nnet_bin" % name] = np.frombuffer(open(P("r.nnet"), "rb").read(), np.uint8)
+        fix["rbm_%s_nnet_txt" % name] = np.frombuffer(open(P("r.txt"), "rb").read(), np.uint8)
+    np.savez_compressed(os.path.join(HERE, "siblings_small.npz"), **fix)
+    print("siblings_small: %d arrays" % len(fix))
+
+
 if __name__ == "__main__":
     if not os.path.exists(os.path.join(BIN, "ref_dump")):
         sys.exit("build the reference first: make -C oracle ref")
@@ -277,3 +340,4 @@ if __name__ == "__main__":
         gen_train_e2e(tmp)
         gen_rbm(tmp)
         gen_rm_shape(tmp)
+        gen_siblings(tmp)

@@ -194,6 +194,73 @@ def test_train_tool_matches_reference(hip, nn, tmp_path, name, opts):
                 np.testing.assert_allclose(a.b, b.b, rtol=5e-5, atol=5e-6)
 
 
+def _model_close(path, ref_bytes, rtol=5e-5, atol=5e-6):
+    got, ref = O.read_nnet(path.read_bytes()), O.read_nnet(ref_bytes)
+    assert [l.marker for l in got] == [l.marker for l in ref]
+    for a, b in zip(got, ref):
+        if isinstance(a, O.BiasedLinearity):
+            np.testing.assert_allclose(a.W, b.W, rtol=rtol, atol=atol)
+            np.testing.assert_allclose(a.b, b.b, rtol=rtol, atol=atol)
+
+
+@pytest.mark.parametrize("name,opts", [("perutt", []), ("perutt_mom", ["--momentum=0.5", "--learn-rate=0.02"])])
+def test_perutt_tool_matches_reference(hip, nn, tmp_path, name, opts):
+    """nnet-train-xent-hardlab-perutt against the reference tool's run on the same archive."""
+    g = load("siblings_small.npz")
+    (tmp_path / "m.nnet").write_bytes(g["model"].tobytes())
+    (tmp_path / "f.ark").write_bytes(g["feats_ark"].tobytes())
+    (tmp_path / "a.ark").write_bytes(g["ali_ark_txt"].tobytes())
+    _, err = run_tool(nn, "nnet-train-xent-hardlab-perutt", ["--binary=true"] + opts + [
+        "ark:" + str(tmp_path / "f.ark"), "ark:" + str(tmp_path / "a.ark"), str(tmp_path / "m.nnet"),
+        str(tmp_path / "out.nnet")])
+    m = re.search(r"Xent:(\S+) frames:(\d+) err/frm:(\S+)\s*\nFRAME_ACCURACY >> (\S+)% <<", err)
+    assert m, err
+    assert int(m.group(2)) == int(g[name + "_frames"])
+    assert m.group(4) == re.search(r">> (\S+)% <<", g[name + "_report"].tobytes().decode()).group(1)   # exact counts
+    assert abs(float(m.group(1)) - float(g[name + "_xent"])) <= 1e-3 * float(g[name + "_xent"])
+    _model_close(tmp_path / "out.nnet", g[name + "_model_out"].tobytes())
+
+
+@pytest.mark.parametrize("name,opts", [
+    ("mse", []), ("mse_cv", ["--cross-validate=true"]),
+    ("mse_mom", ["--momentum=0.9", "--learn-rate=0.05", "--average-grad=true"])])
+def test_mse_tool_matches_reference(hip, nn, tmp_path, name, opts):
+    """nnet-train-mse-tgtmat-frmshuff against the reference tool: same cache sequence (targets carried
+    over and shuffled with the features), same loss, same model."""
+    g = load("siblings_small.npz")
+    (tmp_path / "m.nnet").write_bytes(g["ae_model"].tobytes())
+    (tmp_path / "f.ark").write_bytes(g["feats_ark"].tobytes())
+    (tmp_path / "t.ark").write_bytes(g["tgt_ark"].tobytes())
+    args = ["--bunchsize=16", "--cachesize=64", "--binary=true"] + opts + [
+        "ark:" + str(tmp_path / "f.ark"), "ark:" + str(tmp_path / "t.ark"), str(tmp_path / "m.nnet")]
+    if name != "mse_cv":
+        args.append(str(tmp_path / "out.nnet"))
+    _, err = run_tool(nn, "nnet-train-mse-tgtmat-frmshuff", args)
+    assert "\n".join(re.findall(r"Cache #.*", err)) == g[name + "_cache_lines"].tobytes().decode()
+    m = re.search(r"Mse:(\S+) frames:(\d+) err/frm:(\S+)", err)
+    assert m, err
+    assert int(m.group(2)) == int(g[name + "_frames"])
+    assert abs(float(m.group(1)) - float(g[name + "_loss"])) <= 1e-3 * float(g[name + "_loss"])
+    if name != "mse_cv":
+        _model_close(tmp_path / "out.nnet", g[name + "_model_out"].tobytes())
+
+
+def test_nnet_copy_and_rbm_convert_tools(hip, nn, tmp_path):
+    """Format conversions pass the parameters through the device; files must equal the reference's byte for byte."""
+    g = load("siblings_small.npz")
+    (tmp_path / "m.bin").write_bytes(g["model"].tobytes())
+    run_tool(nn, "nnet-copy", ["--binary=false", str(tmp_path / "m.bin"), str(tmp_path / "m.txt")])
+    assert (tmp_path / "m.txt").read_bytes() == g["copy_txt"].tobytes()
+    run_tool(nn, "nnet-copy", [str(tmp_path / "m.txt"), str(tmp_path / "m2.bin")])
+    assert (tmp_path / "m2.bin").read_bytes() == g["copy_bin"].tobytes()
+    for name in ("bb", "gb", "bg"):
+        (tmp_path / "r.rbm").write_bytes(g["rbm_" + name].tobytes())
+        run_tool(nn, "rbm-convert-to-nnet", ["--binary=true", str(tmp_path / "r.rbm"), str(tmp_path / "r.nnet")])
+        assert (tmp_path / "r.nnet").read_bytes() == g["rbm_%s_nnet_bin" % name].tobytes()
+        run_tool(nn, "rbm-convert-to-nnet", [str(tmp_path / "r.rbm"), str(tmp_path / "r.txt")])
+        assert (tmp_path / "r.txt").read_bytes() == g["rbm_%s_nnet_txt" % name].tobytes()
+
+
 def test_train_tool_text_model_and_usage(hip, nn, tmp_path):
     g = load("train_e2e_small.npz")
     (tmp_path / "m.nnet").write_bytes(g["model"].tobytes())

@@ -45,7 +45,9 @@ def test_host_random_stream_is_glibc_rand():
 
 
 def test_tools_print_usage_without_gpu():
-    for tool, n in [("nnet-forward", 3), ("nnet-train-xent-hardlab-frmshuff", 4), ("rbm-train-cd1-frmshuff", 3)]:
+    for tool, n in [("nnet-forward", 3), ("nnet-train-xent-hardlab-frmshuff", 4), ("rbm-train-cd1-frmshuff", 3),
+                    ("nnet-train-xent-hardlab-perutt", 4), ("nnet-train-mse-tgtmat-frmshuff", 4), ("nnet-copy", 2),
+                    ("rbm-convert-to-nnet", 2)]:
         exe = os.path.join(ROOT, "kaldi_amd", "bin", tool)
         r = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
         assert r.returncode == 1

@@ -219,6 +219,96 @@ def test_rm_shape_step_matches_reference():
         close(l.b, g["b%d" % i], rtol=1e-5, atol=1e-7)
 
 
+def _alis(g):
+    alis = {}
+    for line in g["ali_ark_txt"].tobytes().decode().splitlines():
+        parts = line.split()
+        alis[parts[0]] = np.array(parts[1:], np.int32)
+    return alis
+
+
+def _check_models(net, ref_bytes, rtol=5e-5, atol=5e-6):
+    for a, b in zip(net.layers, O.read_nnet(ref_bytes)):
+        if isinstance(a, O.BiasedLinearity):
+            close(a.W, b.W, rtol=rtol, atol=atol)
+            close(a.b, b.b, rtol=rtol, atol=atol)
+
+
+@pytest.mark.parametrize("name,opts", [("perutt", dict(learn_rate=0.008)),
+                                       ("perutt_mom", dict(learn_rate=0.02, momentum=0.5))])
+def test_perutt_trainer_matches_reference(name, opts):
+    """nnet-train-xent-hardlab-perutt: one update per utterance, in archive order."""
+    g = load("siblings_small.npz")
+    net = O.Nnet(O.read_nnet(g["model"].tobytes()))
+    net.set_train_opts(**opts)
+    alis, xent = _alis(g), O.Xent()
+    for key, mat in O.read_matrix_ark(g["feats_ark"].tobytes()):
+        diff, _, _, _ = xent.eval_vec(net.propagate(mat), alis[key])
+        net.backpropagate(diff)
+    assert xent.frames == int(g[name + "_frames"])
+    assert abs(xent.loss - float(g[name + "_xent"])) <= 2e-5 * abs(xent.loss)
+    assert xent.report().split("\n")[1] == g[name + "_report"].tobytes().decode().split("\n")[1]
+    _check_models(net, g[name + "_model_out"].tobytes())
+
+
+@pytest.mark.parametrize("name,opts", [("mse", dict(learn_rate=0.008)), ("mse_cv", dict(learn_rate=0.0)),
+                                       ("mse_mom", dict(learn_rate=0.05, momentum=0.9, average_grad=True))])
+def test_mse_trainer_matches_reference(name, opts):
+    """nnet-train-mse-tgtmat-frmshuff: the frame cache with a target matrix per utterance; the
+    targets ride through the oracle's cache as row numbers into their concatenation."""
+    g = load("siblings_small.npz")
+    net = O.Nnet(O.read_nnet(g["ae_model"].tobytes()))
+    net.set_train_opts(**opts)
+    feats = O.read_matrix_ark(g["feats_ark"].tobytes())
+    tgts = O.read_matrix_ark(g["tgt_ark"].tobytes())
+    all_t = np.concatenate([m for _, m in tgts])
+    starts = np.cumsum([0] + [m.shape[0] for _, m in tgts])
+    cache = O.Cache(64, 16)
+    cache_lines, pos, num_done, tot, loss = [], 0, 0, 0, 0.0
+    O.srand(1)
+    while True:
+        while not cache.full() and pos < len(feats):
+            key, mat = feats[pos]
+            assert tgts[pos][0] == key
+            cache.add_data(mat, np.arange(starts[pos], starts[pos + 1], dtype=np.int32))
+            num_done += 1
+            pos += 1
+        if name != "mse_cv":
+            mask = list(range(cache.filling_pos))
+            for i in range(1, len(mask)):
+                j = O.rand_int(0, i)
+                mask[i], mask[j] = mask[j], mask[i]
+            cache.randomize(mask)
+        cache_lines.append("Cache #%d %s segments: %d frames: %d" % (len(cache_lines) + 1,
+                                                                      "[RND]" if cache.randomized else "[NO-RND]",
+                                                                      num_done, tot))
+        while not cache.empty():
+            x, ids = cache.get_bunch()
+            diff, _, l = O.mse_eval(net.propagate(x), all_t[np.asarray(ids)])
+            loss += l
+            if opts["learn_rate"] > 0:
+                net.backpropagate(diff)
+            tot += x.shape[0]
+        if pos >= len(feats):
+            break
+    assert "\n".join(cache_lines) == g[name + "_cache_lines"].tobytes().decode()
+    assert tot == int(g[name + "_frames"])
+    assert abs(loss - float(g[name + "_loss"])) <= 5e-5 * abs(loss)
+    if name != "mse_cv":
+        _check_models(net, g[name + "_model_out"].tobytes())
+
+
+def test_nnet_copy_and_rbm_convert_match_reference_bytes():
+    g = load("siblings_small.npz")
+    layers = O.read_nnet(g["model"].tobytes())
+    assert O.write_nnet(layers, False) == g["copy_txt"].tobytes()
+    assert O.write_nnet(O.read_nnet(g["copy_txt"].tobytes()), True) == g["copy_bin"].tobytes()
+    for name in ("bb", "gb", "bg"):
+        rbm = O.read_nnet(g["rbm_" + name].tobytes())[0]
+        assert O.write_rbm_as_nnet(rbm, True) == g["rbm_%s_nnet_bin" % name].tobytes()
+        assert O.write_rbm_as_nnet(rbm, False) == g["rbm_%s_nnet_txt" % name].tobytes()
+
+
 def test_libc_rand_helpers():
     O.srand(1)
     a = [O.rand_int(0, 99) for _ in range(5)]
