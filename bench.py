@@ -201,6 +201,7 @@ def main():
         else:
             trainer = nn.Trainer(model_path)
             trainer.set_train_opts(0.008)
+            trainer.keep_posteriors(False)   # like the tool: only the loss and its gradient leave the output layer
             if world > 1:
                 trainer.set_data_parallel(world)
         # a synthetic, already shuffled frame cache resident in HBM (each rank its own frames)

@@ -307,6 +307,16 @@ int hipF_affine_apply(khStream_t s, int32_t O, int32_t I, const float *grad, int
 int hipF_xent_eval(khStream_t s, const float *post, const int32_t *tgt, float *diff, float *log_post,
                    int32_t *max_id, long long *counters, double *loss, MatrixDim d);
 
+/* The output layer of a training step in one call: hipF_affine_forward with KH_ACT_SOFTMAX followed by
+ * hipF_xent_eval (nnet-biasedlinearity.h:58-63 + nnet-activation.h:233-236 + nnet-loss.cc:59-94), with the
+ * posteriors kept in registers between the two.  Same results as the two calls.  post is always a valid N x O
+ * buffer (ldpost == lddiff); with write_post == 0 its contents are unspecified afterwards (the trainer only
+ * needs diff).  log_post / max_id may be NULL. */
+int hipF_affine_forward_xent(khStream_t s, int trans_w, int32_t N, int32_t O, int32_t I, const float *in,
+                             int32_t ldin, const float *W, int32_t ldw, const float *bias, float *post,
+                             int32_t ldpost, int write_post, const int32_t *tgt, float *diff, int32_t lddiff,
+                             float *log_post, int32_t *max_id, long long *counters, double *loss);
+
 /* MseProgress::Eval / Mse::Eval (nnet-loss.cc:123-194): diff = a - b (may be NULL);
  * loss[0] += 0.5 * sum (a-b)^2 (double on device); per-row sums in row_sq (may be NULL). */
 int hipF_mse_eval(khStream_t s, const float *a, const float *b, float *diff, float *row_sq, double *loss,

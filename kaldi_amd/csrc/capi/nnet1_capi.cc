@@ -19,6 +19,7 @@ struct Trainer {
   Xent xent;
   CuMatrix<BaseFloat> nnet_in, nnet_out, glob_err;
   CuStlVector<int32> targets;
+  bool keep_posteriors = true;
 };
 
 struct RbmTrainer {
@@ -108,9 +109,15 @@ int nnet1_train_bunch(void *h, const float *feats_dev, int ld, int rows, int col
   t->nnet_in.AttachView(const_cast<float *>(feats_dev), rows, cols, ld);
   t->targets.AttachView(const_cast<int32 *>(labels_dev), rows);
   t->nnet.SetBorrowInput(true);
-  t->nnet.Propagate(t->nnet_in, &t->nnet_out);
-  t->xent.EvalVec(t->nnet_out, t->targets, &t->glob_err);
+  t->nnet.PropagateXent(t->nnet_in, t->targets, &t->xent, &t->nnet_out, &t->glob_err, t->keep_posteriors);
   if (!cross_validate) t->nnet.Backpropagate(t->glob_err, NULL);
+  return 0;
+  CAPI_CATCH(-1)
+}
+
+int nnet1_keep_posteriors(void *h, int keep) {
+  CAPI_TRY
+  static_cast<Trainer *>(h)->keep_posteriors = keep != 0;
   return 0;
   CAPI_CATCH(-1)
 }

@@ -23,6 +23,9 @@ int nnet1_set_data_parallel(void *h, int nranks);
  * (cache) buffer, Propagate, Xent::EvalVec, Backpropagate (skipped when cross_validate != 0) */
 int nnet1_train_bunch(void *h, const float *feats_dev, int ld, int rows, int cols, const int32_t *labels_dev,
                       int cross_validate);
+/* keep != 0 (default): the posteriors of the last bunch stay readable (nnet1_get_posteriors);
+ * 0: the training step never writes them (the output layer, its softmax and the loss are fused) */
+int nnet1_keep_posteriors(void *h, int keep);
 /* Nnet::Feedforward; out_dev is rows x output_dim with leading dimension ld_out */
 int nnet1_feedforward(void *h, const float *feats_dev, int ld, int rows, int cols, float *out_dev, int ld_out);
 int nnet1_get_stats(void *h, long long *frames, long long *correct, double *loss);

@@ -42,6 +42,18 @@ int ensure_workspace(hipStream_t st, size_t bytes, void **ptr);
 // The arrival counter of stream `st` (device memory, zero whenever no kernel that uses it is queued).
 int stream_ticket(hipStream_t st, unsigned **ticket);
 
+// What the row-softmax finish of a GEMM needs to go on to Xent::EvalVec in the same kernel.
+struct XentArgs {
+  const int32_t *tgt;
+  float *diff;
+  int lddiff;
+  float *log_post;   // may be NULL (library scratch)
+  int32_t *max_id;   // may be NULL
+  long long *counters;
+  double *loss;
+  int write_post;    // 0: the posteriors themselves are not wanted
+};
+
 inline int launch_status() {
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? KH_OK : (int)e;

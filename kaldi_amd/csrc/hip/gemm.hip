@@ -29,7 +29,7 @@
 
 namespace kh {
 int softmax_slabs_launch(hipStream_t st, float *y, int ldy, const float *x, int ldx, int nslab, size_t slab_stride,
-                         const float *bias, int rows, int cols);
+                         const float *bias, int rows, int cols, const XentArgs *xent);
 }
 
 #ifndef KH_SCHED
@@ -897,7 +897,8 @@ struct TimedLaunch {
 // Runs op(A)*op(B) and the epilogue EPI.  `softmax` selects the row-softmax finish (always via
 // slabs, since a row spans many tiles).
 template <int EPI>
-int run_gemm(khStream_t s, bool a_kmajor, bool b_kmajor, GemmParams p, bool allow_split, bool softmax = false) {
+int run_gemm(khStream_t s, bool a_kmajor, bool b_kmajor, GemmParams p, bool allow_split, bool softmax = false,
+             const kh::XentArgs *xent = nullptr) {
   hipStream_t st = kh::pick(s);
   const bool vec = kh::aligned16(p.A) && kh::aligned16(p.B) && (p.lda % 4 == 0) && (p.ldb % 4 == 0);
   Plan plan = make_plan(p.M, p.N, p.K, kh::ctx().num_cu > 0 ? kh::ctx().num_cu : 256, allow_split || softmax,
@@ -925,7 +926,8 @@ int run_gemm(khStream_t s, bool a_kmajor, bool b_kmajor, GemmParams p, bool allo
   const int ld_slab = (p.N + 3) & ~3;
   const size_t slab_stride = (size_t)p.M * ld_slab;
   void *ws;
-  int rc = kh::ensure_workspace(st, slab_stride * p.splitk * sizeof(float), &ws);
+  // (+ 8 bytes per row: per-row results of the fused softmax / cross-entropy finish)
+  int rc = kh::ensure_workspace(st, slab_stride * p.splitk * sizeof(float) + (xent ? (size_t)p.M * 8 : 0), &ws);
   if (rc != KH_OK) return rc;
   GemmParams ps = p;
   ps.C = (float *)ws;
@@ -940,7 +942,7 @@ int run_gemm(khStream_t s, bool a_kmajor, bool b_kmajor, GemmParams p, bool allo
   p.slab_stride = slab_stride;
   if (softmax)
     return kh::softmax_slabs_launch(st, p.C, p.ldc, (const float *)ws, ld_slab, p.splitk, slab_stride, p.bias, p.M,
-                                    p.N);
+                                    p.N, xent);
   launch_reduce<EPI>(st, p, (const float *)ws, ld_slab);
   return kh::launch_status();
 }
@@ -1186,6 +1188,33 @@ KH_EXPORT int hipF_affine_forward(khStream_t s, int act, int trans_w, int32_t N,
   p.bias = bias;
   p.act = act;
   return run_gemm<EPI_BIAS_ACT>(s, true, b_kmajor, p, true, act == KH_ACT_SOFTMAX);
+}
+
+KH_EXPORT int hipF_affine_forward_xent(khStream_t s, int trans_w, int32_t N, int32_t O, int32_t I, const float *in,
+                                       int32_t ldin, const float *W, int32_t ldw, const float *bias, float *post,
+                                       int32_t ldpost, int write_post, const int32_t *tgt, float *diff, int32_t lddiff,
+                                       float *log_post, int32_t *max_id, long long *counters, double *loss) {
+  KH_CHECK_INIT();
+  KH_REQUIRE(trans_w == KH_TRANS || trans_w == KH_NO_TRANS);
+  KH_REQUIRE(N >= 0 && O > 0 && I > 0);
+  if (N == 0) return KH_OK;
+  KH_REQUIRE(in && W && bias && post && ldin >= I && ldpost >= O);
+  KH_REQUIRE(tgt && diff && diff != post && lddiff == ldpost && counters && loss);
+  const bool b_kmajor = (trans_w == KH_TRANS);
+  KH_REQUIRE(ldw >= (b_kmajor ? I : O));
+  GemmParams p = base_params(N, O, I, in, ldin, W, ldw, post, ldpost);
+  p.bias = bias;
+  p.act = KH_ACT_SOFTMAX;
+  kh::XentArgs xa;
+  xa.tgt = tgt;
+  xa.diff = diff;
+  xa.lddiff = lddiff;
+  xa.log_post = log_post;
+  xa.max_id = max_id;
+  xa.counters = counters;
+  xa.loss = loss;
+  xa.write_post = write_post;
+  return run_gemm<EPI_BIAS_ACT>(s, true, b_kmajor, p, true, true, &xa);
 }
 
 KH_EXPORT int hipF_affine_backward(khStream_t s, int32_t N, int32_t O, int32_t I, const float *e, int32_t lde,

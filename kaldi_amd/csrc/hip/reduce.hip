@@ -96,17 +96,13 @@ __global__ __launch_bounds__(kSoftmaxThreads) void softmax_kernel(float *y, int 
 // Register-resident form: every thread owns NV float4 of the row (slabs and bias summed in the same
 // order as above), all loads in flight together, one read and one write of the row.  Needs 16-byte
 // aligned rows / slabs / bias and cols <= 4 * kSoftmaxThreads * NV.
+// The row in registers: v[] receives exp(x - max) of this thread's columns (0 past the end), the
+// return value is 1 / sum.
 template <int NV>
-__global__ __launch_bounds__(kSoftmaxThreads) void softmax_vec_kernel(float *y, int ldy, const float *x, int ldx,
-                                                                      int nslab, size_t slab_stride,
-                                                                      const float *bias, int cols) {
-  __shared__ float red[16];
-  const int r = blockIdx.x;
-  const float *px = x + (size_t)r * ldx;
-  float *py = y + (size_t)r * ldy;
+__device__ __forceinline__ float softmax_row_regs(float4 (&v)[NV], const float *px, int nslab, size_t slab_stride,
+                                                  const float *bias, int cols, float *red) {
   const int t = threadIdx.x;
   const int cols4 = (cols + 3) & ~3;  // whole float4s inside the padded row
-  float4 v[NV];
 #pragma unroll
   for (int k = 0; k < NV; ++k) {
     const int c = (t + k * kSoftmaxThreads) * 4;
@@ -157,18 +153,29 @@ __global__ __launch_bounds__(kSoftmaxThreads) void softmax_vec_kernel(float *y, 
     sum += (v[k].x + v[k].y) + (v[k].z + v[k].w);
   }
   sum = kh::block_sum(sum, red);
-  const float inv = 1.0f / sum;
-#pragma unroll
-  for (int k = 0; k < NV; ++k) {
-    const int c = (t + k * kSoftmaxThreads) * 4;
-    if (c + 3 < cols) {
-      *reinterpret_cast<float4 *>(py + c) = make_float4(v[k].x * inv, v[k].y * inv, v[k].z * inv, v[k].w * inv);
-    } else if (c < cols) {
-      py[c] = v[k].x * inv;
-      if (c + 1 < cols) py[c + 1] = v[k].y * inv;
-      if (c + 2 < cols) py[c + 2] = v[k].z * inv;
-    }
+  return 1.0f / sum;
+}
+__device__ __forceinline__ void store_row4(float *py, int c, int cols, float a, float b, float cc, float d) {
+  if (c + 3 < cols) {
+    *reinterpret_cast<float4 *>(py + c) = make_float4(a, b, cc, d);
+  } else if (c < cols) {
+    py[c] = a;
+    if (c + 1 < cols) py[c + 1] = b;
+    if (c + 2 < cols) py[c + 2] = cc;
   }
+}
+template <int NV>
+__global__ __launch_bounds__(kSoftmaxThreads) void softmax_vec_kernel(float *y, int ldy, const float *x, int ldx,
+                                                                      int nslab, size_t slab_stride,
+                                                                      const float *bias, int cols) {
+  __shared__ float red[16];
+  const int r = blockIdx.x;
+  float *py = y + (size_t)r * ldy;
+  float4 v[NV];
+  const float inv = softmax_row_regs<NV>(v, x + (size_t)r * ldx, nslab, slab_stride, bias, cols, red);
+#pragma unroll
+  for (int k = 0; k < NV; ++k)
+    store_row4(py, (threadIdx.x + k * kSoftmaxThreads) * 4, cols, v[k].x * inv, v[k].y * inv, v[k].z * inv, v[k].w * inv);
 }
 
 __global__ __launch_bounds__(256) void softmax_part_kernel(const float *X, const int32_t *ids, float *Y,
@@ -265,25 +272,29 @@ __global__ void diff_xent_kernel(const int32_t *tgt, float *mat, float *log_post
 // pass 2: counters and loss in a fixed order, by one workgroup
 __device__ __forceinline__ void xent_accum_block(const int32_t *tgt, const float *log_post, const int32_t *max_id,
                                                  long long *counters, double *loss, int rows) {
+  // the first 256 threads of the workgroup do the work (callers have 256 or more)
   __shared__ double sd[256];
   __shared__ int sc[256];
-  double acc = 0.0;
-  int correct = 0;
-  for (int r = threadIdx.x; r < rows; r += 256) {
-    acc += (double)log_post[r];
-    correct += (max_id[r] == tgt[r]) ? 1 : 0;
+  const int t = threadIdx.x;
+  if (t < 256) {
+    double acc = 0.0;
+    int correct = 0;
+    for (int r = t; r < rows; r += 256) {
+      acc += (double)log_post[r];
+      correct += (max_id[r] == tgt[r]) ? 1 : 0;
+    }
+    sd[t] = acc;
+    sc[t] = correct;
   }
-  sd[threadIdx.x] = acc;
-  sc[threadIdx.x] = correct;
   __syncthreads();
   for (int o = 128; o > 0; o >>= 1) {
-    if (threadIdx.x < o) {
-      sd[threadIdx.x] += sd[threadIdx.x + o];
-      sc[threadIdx.x] += sc[threadIdx.x + o];
+    if (t < o) {
+      sd[t] += sd[t + o];
+      sc[t] += sc[t + o];
     }
     __syncthreads();
   }
-  if (threadIdx.x == 0) {
+  if (t == 0) {
     counters[0] += sc[0];
     counters[1] += rows;
     loss[0] -= sd[0];
@@ -417,6 +428,88 @@ __global__ __launch_bounds__(256) void xent_rows_vec_kernel(const float *post, c
   }
   xent_finish(tail, tgt, log_post, max_id, d.rows);
 }
+// Softmax finish of the output layer's GEMM and Xent::EvalVec in one pass: the posteriors of a row
+// never leave the registers between the two (they are stored only when the caller wants them).
+// Arg-max, target posterior and diff are taken from the same rounded posteriors the two-kernel
+// path stores and re-reads, so counts and sums are identical to it.
+struct XentFuse {
+  const int32_t *tgt;
+  float *diff;
+  int lddiff;
+  float *log_post;
+  int32_t *max_id;
+  int write_post;
+  int rows;
+  XentTail tail;
+};
+template <int NV>
+__global__ __launch_bounds__(kSoftmaxThreads) void softmax_xent_vec_kernel(float *y, int ldy, const float *x, int ldx,
+                                                                           int nslab, size_t slab_stride,
+                                                                           const float *bias, int cols, XentFuse xf) {
+  __shared__ float red[16];
+  __shared__ float sv[8];
+  __shared__ int32_t si[8];
+  __shared__ float spt[8];
+  const int r = blockIdx.x;
+  float4 v[NV];
+  const float inv = softmax_row_regs<NV>(v, x + (size_t)r * ldx, nslab, slab_stride, bias, cols, red);
+  const int t = xf.tgt[r];
+  const bool t_ok = (t >= 0 && t < cols);
+  float *py = y + (size_t)r * ldy;
+  float *pd = xf.diff + (size_t)r * xf.lddiff;
+  MaxId m;
+  m.v = -1e21f;
+  m.i = -1;
+  float pt = 0.0f;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const int c = (threadIdx.x + k * kSoftmaxThreads) * 4;
+    float e[4] = {v[k].x * inv, v[k].y * inv, v[k].z * inv, v[k].w * inv};
+    if (xf.write_post) store_row4(py, c, cols, e[0], e[1], e[2], e[3]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (c + j < cols) {
+        if (e[j] > m.v) {
+          m.v = e[j];
+          m.i = c + j;
+        }
+        if (c + j == t) {
+          pt = e[j];
+          e[j] -= 1.0f;
+        }
+      }
+    }
+    store_row4(pd, c, cols, e[0], e[1], e[2], e[3]);
+  }
+  m = wave_best(m);  // per-thread columns ascend, lower index wins ties: the first maximum of the row
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) pt += __shfl_xor(pt, o, 64);  // the target's posterior lives in one thread
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  if (lane == 0) {
+    sv[wid] = m.v;
+    si[wid] = m.i;
+    spt[wid] = pt;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    MaxId b;
+    b.v = sv[0];
+    b.i = si[0];
+    float ptot = spt[0];
+    for (int w = 1; w < kSoftmaxThreads / 64; ++w) {
+      MaxId o;
+      o.v = sv[w];
+      o.i = si[w];
+      b = better(b, o);
+      ptot += spt[w];
+    }
+    xf.max_id[r] = b.i;
+    const float ptv = t_ok ? ptot : 0.0f;
+    xf.log_post[r] = logf(ptv < 1e-20f ? 1e-20f : ptv);
+  }
+  xent_finish(xf.tail, xf.tgt, xf.log_post, xf.max_id, xf.rows);
+}
+
 // ---- fused Mse / MseProgress Eval ------------------------------------------------------------
 __global__ __launch_bounds__(256) void mse_rows_kernel(const float *a, const float *b, float *diff, float *row_sq,
                                                        MatrixDim d) {
@@ -449,9 +542,41 @@ __global__ __launch_bounds__(256) void mse_accum_kernel(const float *row_sq, dou
 
 namespace kh {
 int softmax_slabs_launch(hipStream_t st, float *y, int ldy, const float *x, int ldx, int nslab, size_t slab_stride,
-                         const float *bias, int rows, int cols) {
+                         const float *bias, int rows, int cols, const XentArgs *xent) {
   const bool vec = (ldx % 4 == 0) && (ldy % 4 == 0) && (slab_stride % 4 == 0) && kh::aligned16(x) && kh::aligned16(y) &&
                    (!bias || kh::aligned16(bias));
+  if (xent && vec && cols <= 4 * kSoftmaxThreads * 5 && xent->lddiff % 4 == 0 && kh::aligned16(xent->diff) &&
+      xent->diff != y) {
+    XentFuse xf;
+    xf.tgt = xent->tgt;
+    xf.diff = xent->diff;
+    xf.lddiff = xent->lddiff;
+    xf.log_post = xent->log_post;
+    xf.max_id = xent->max_id;
+    xf.write_post = xent->write_post;
+    xf.rows = rows;
+    xf.tail.counters = xent->counters;
+    xf.tail.loss = xent->loss;
+    int rc = kh::stream_ticket(st, &xf.tail.ticket);
+    if (rc != KH_OK) return rc;
+    if (!xf.log_post || !xf.max_id) {
+      // per-row results nobody asked for go behind the slabs in the stream's workspace
+      void *ws;
+      const size_t slabs = (size_t)nslab * slab_stride * sizeof(float);
+      rc = kh::ensure_workspace(st, slabs + (size_t)rows * 8, &ws);
+      if (rc != KH_OK) return rc;
+      if ((const void *)x != ws) return KH_ERR_INVALID_ARG;  // the slabs must be that workspace's (they are: run_gemm)
+      if (!xf.log_post) xf.log_post = (float *)((char *)ws + slabs);
+      if (!xf.max_id) xf.max_id = (int32_t *)((char *)ws + slabs + (size_t)rows * 4);
+    }
+    if (cols <= 4 * kSoftmaxThreads * 2)
+      hipLaunchKernelGGL((softmax_xent_vec_kernel<2>), dim3(rows), dim3(kSoftmaxThreads), 0, st, y, ldy, x, ldx, nslab,
+                         slab_stride, bias, cols, xf);
+    else
+      hipLaunchKernelGGL((softmax_xent_vec_kernel<5>), dim3(rows), dim3(kSoftmaxThreads), 0, st, y, ldy, x, ldx, nslab,
+                         slab_stride, bias, cols, xf);
+    return kh::launch_status();
+  }
   if (vec && cols <= 4 * kSoftmaxThreads * 2)
     hipLaunchKernelGGL((softmax_vec_kernel<2>), dim3(rows), dim3(kSoftmaxThreads), 0, st, y, ldy, x, ldx, nslab,
                        slab_stride, bias, cols);
@@ -464,7 +589,13 @@ int softmax_slabs_launch(hipStream_t st, float *y, int ldy, const float *x, int 
   else
     hipLaunchKernelGGL((softmax_kernel<false>), dim3(rows), dim3(kSoftmaxThreads), 0, st, y, ldy, x, ldx, nslab,
                        slab_stride, bias, cols);
-  return kh::launch_status();
+  int rc = kh::launch_status();
+  if (rc != KH_OK || !xent) return rc;
+  // two-kernel form of the same thing (shapes the fused kernel does not take)
+  MatrixDim d = {rows, cols, ldy};
+  if (xent->lddiff != ldy) return KH_ERR_INVALID_ARG;
+  return hipF_xent_eval((khStream_t)st, y, xent->tgt, xent->diff, xent->log_post, xent->max_id, xent->counters,
+                        xent->loss, d);
 }
 }  // namespace kh
 
@@ -494,7 +625,7 @@ KH_EXPORT int hipF_softmax(khStream_t s, float *y, const float *x, MatrixDim d) 
   KH_REQUIRE(kh::dim_ok(d));
   if (d.rows == 0 || d.cols == 0) return KH_OK;
   KH_REQUIRE(y != nullptr && x != nullptr);
-  return kh::softmax_slabs_launch(kh::pick(s), y, d.stride, x, d.stride, 1, 0, nullptr, d.rows, d.cols);
+  return kh::softmax_slabs_launch(kh::pick(s), y, d.stride, x, d.stride, 1, 0, nullptr, d.rows, d.cols, nullptr);
 }
 
 KH_EXPORT int hipF_softmax_part(khStream_t s, const float *X, const int32_t *vec_ids, float *Y, MatrixDim d) {

@@ -5,6 +5,7 @@
 #ifndef KALDI_AMD_NNET_NNET_BIASEDLINEARITY_H_
 #define KALDI_AMD_NNET_NNET_BIASEDLINEARITY_H_
 #include "cudamatrix/cu-math.h"
+#include "cudamatrix/cu-stlvector.h"
 #include "nnet/nnet-component.h"
 
 namespace kaldi {
@@ -43,6 +44,22 @@ class BiasedLinearity : public UpdatableComponent {
     if (input_dim_ != in.NumCols()) KALDI_ERR << "Nonmatching dims, component:" << input_dim_ << " data:" << in.NumCols();
     if (output_dim_ != out->NumCols() || in.NumRows() != out->NumRows()) out->Resize(in.NumRows(), output_dim_);
     Forward(in, act, out);
+  }
+  /// The output layer of a training step: softmax(in * W^T + b) and Xent::EvalVec against the labels
+  /// in one pass (diff = posteriors - onehot).  `out` gets the posteriors only if write_post.
+  void PropagateFusedXent(const CuMatrix<BaseFloat> &in, const CuStlVector<int32> &target, bool write_post,
+                          CuMatrix<BaseFloat> *out, CuMatrix<BaseFloat> *diff, BaseFloat *log_post, int32 *max_id,
+                          long long *counters, double *loss) {
+    CuProfileScope p("BiasedLinearity::PropagateXent");
+    if (input_dim_ != in.NumCols()) KALDI_ERR << "Nonmatching dims, component:" << input_dim_ << " data:" << in.NumCols();
+    KALDI_ASSERT(static_cast<int32>(target.Dim()) == in.NumRows() && out != diff);
+    if (output_dim_ != out->NumCols() || in.NumRows() != out->NumRows()) out->Resize(in.NumRows(), output_dim_);
+    if (output_dim_ != diff->NumCols() || in.NumRows() != diff->NumRows()) diff->Resize(in.NumRows(), output_dim_);
+    KALDI_ASSERT(out->Stride() == diff->Stride());
+    CU_SAFE_CALL(hipF_affine_forward_xent(S(), KH_TRANS, in.NumRows(), output_dim_, input_dim_, in.Data(), in.Stride(),
+                                          linearity_.Data(), linearity_.Stride(), bias_.Data(), out->Data(), out->Stride(),
+                                          write_post ? 1 : 0, target.Data(), diff->Data(), diff->Stride(), log_post, max_id,
+                                          counters, loss));
   }
   /// out_err = (in_err * W) .* y .* (1-y): this layer's backprop followed by that of the sigmoid
   /// that produced this layer's input y

@@ -42,6 +42,17 @@ class Xent {
   /// same with the labels already on the device (no host<->device traffic at all)
   void EvalVec(const CuMatrix<BaseFloat> &net_out, const CuStlVector<int32> &target, CuMatrix<BaseFloat> *diff);
 
+  /// For a kernel that evaluates the loss itself (Nnet::PropagateXent): the per-frame vectors sized
+  /// for `rows` frames and the running device counters, exactly what EvalVec hands to its kernel.
+  void FusedBuffers(int32 rows, BaseFloat **log_post, int32 **max_id, long long **counters, double **loss) {
+    max_id_.Resize(rows);
+    log_post_tgt_.Resize(rows);
+    *log_post = log_post_tgt_.Data();
+    *max_id = max_id_.Data();
+    *counters = stats_.Counters();
+    *loss = stats_.Loss();
+  }
+
   std::string Report();
   void Reset();
   BaseFloat GetFrameAccuracy();

@@ -1,5 +1,7 @@
 #include "nnet/nnet-nnet.h"
 
+#include "nnet/nnet-loss.h"
+
 #include <stdlib.h>
 #include <string.h>
 
@@ -71,6 +73,44 @@ void Nnet::Propagate(const CuMatrix<BaseFloat> &in, CuMatrix<BaseFloat> *out) {
     out->Swap(&last);
   } else {
     out->CopyFromMat(last);
+  }
+}
+
+void Nnet::PropagateXent(const CuMatrix<BaseFloat> &in, const CuStlVector<int32> &target, Xent *xent,
+                         CuMatrix<BaseFloat> *out, CuMatrix<BaseFloat> *diff, bool keep_output) {
+  KALDI_ASSERT(NULL != out && NULL != diff && NULL != xent);
+  const int32 L = LayerCount();
+  static const bool two_calls = getenv("KALDI_AMD_UNFUSED_LOSS") != NULL;  // for A/B measurements
+  const bool fusable = !two_calls && fusion_ && L >= 2 && nnet_[L - 1]->GetType() == Component::kSoftmax &&
+                       nnet_[L - 2]->GetType() == Component::kBiasedLinearity;
+  if (!fusable) {
+    Propagate(in, out);
+    xent->EvalVec(*out, target, diff);
+    return;
+  }
+  KALDI_ASSERT(static_cast<int32>(propagate_buf_.size()) >= L + 1);
+  if (borrow_input_) propagate_buf_[0].AttachRows(in, 0, in.NumRows());
+  else propagate_buf_[0].CopyFromMat(in);
+  for (int32 i = 0; i < L - 2; ++i) {
+    const int act = ActivationAfter(nnet_, i);
+    if (act >= 0) {
+      static_cast<BiasedLinearity *>(nnet_[i])->PropagateFused(propagate_buf_[i], act, &propagate_buf_[i + 2]);
+      ++i;
+    } else {
+      nnet_[i]->Propagate(propagate_buf_[i], &propagate_buf_[i + 1]);
+    }
+  }
+  BaseFloat *log_post;
+  int32 *max_id;
+  long long *counters;
+  double *loss;
+  xent->FusedBuffers(in.NumRows(), &log_post, &max_id, &counters, &loss);
+  CuMatrix<BaseFloat> &last = propagate_buf_[L];
+  static_cast<BiasedLinearity *>(nnet_[L - 2])
+      ->PropagateFusedXent(propagate_buf_[L - 2], target, keep_output, &last, diff, log_post, max_id, counters, loss);
+  if (keep_output) {
+    if (out->NumRows() == last.NumRows() && out->NumCols() == last.NumCols()) out->Swap(&last);
+    else out->CopyFromMat(last);
   }
 }
 

@@ -24,6 +24,8 @@
 
 namespace kaldi {
 
+class Xent;
+
 class Nnet {
  public:
   Nnet() : learn_rate_(0.0), fusion_(true), overlap_(true), borrow_input_(false), dp_ranks_(1), dp_grad_(NULL), dp_grad_size_(0), join_event_(NULL), aux_join_event_(NULL) {}
@@ -31,6 +33,12 @@ class Nnet {
 
   /// forward pass, keeping every layer's output for Backpropagate
   void Propagate(const CuMatrix<BaseFloat> &in, CuMatrix<BaseFloat> *out);
+  /// Propagate followed by xent->EvalVec(*out, target, diff).  When the network ends in
+  /// <biasedlinearity><softmax> and fusion is on, the output layer, the softmax and the loss are one
+  /// GEMM + one row kernel, and with keep_output == false the posteriors are never written (*out is
+  /// then unspecified).  Not in the reference.
+  void PropagateXent(const CuMatrix<BaseFloat> &in, const CuStlVector<int32> &target, Xent *xent,
+                     CuMatrix<BaseFloat> *out, CuMatrix<BaseFloat> *diff, bool keep_output);
   /// backward pass + parameter update; out_err == NULL skips the input gradient of layer 0
   void Backpropagate(const CuMatrix<BaseFloat> &in_err, CuMatrix<BaseFloat> *out_err);
   /// forward pass that keeps two ping-pong buffers only (inference)

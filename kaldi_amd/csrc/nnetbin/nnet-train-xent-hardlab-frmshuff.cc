@@ -144,8 +144,7 @@ int main(int argc, char *argv[]) {
         while (!cache.Empty()) {
           if (fused) cache.GetBunchView(&nnet_in, &targets);
           else cache.GetBunch(&nnet_in, &targets);
-          nnet.Propagate(nnet_in, &nnet_out);
-          xent.EvalVec(nnet_out, targets, &glob_err);
+          nnet.PropagateXent(nnet_in, targets, &xent, &nnet_out, &glob_err, false);  // nothing reads the posteriors here
           if (!crossvalidate) nnet.Backpropagate(glob_err, NULL);
           tot_t += nnet_in.NumRows();
         }
@@ -156,8 +155,7 @@ int main(int argc, char *argv[]) {
         for (int64 b = 0; b < bunches; ++b) {
           if (fused) cache.GetBunchView(&nnet_in, &targets);
           else cache.GetBunch(&nnet_in, &targets);
-          nnet.Propagate(nnet_in, &nnet_out);
-          xent.EvalVec(nnet_out, targets, &glob_err);
+          nnet.PropagateXent(nnet_in, targets, &xent, &nnet_out, &glob_err, false);  // nothing reads the posteriors here
           if (!crossvalidate) nnet.Backpropagate(glob_err, NULL);
           tot_t += nnet_in.NumRows();
         }

@@ -26,6 +26,7 @@ _SIGS = {
     "nnet1_set_data_parallel": (I, [P, I]),
     "nnet1_train_bunch": (I, [P, P, I, I, I, P, I]),
     "nnet1_feedforward": (I, [P, P, I, I, I, P, I]),
+    "nnet1_keep_posteriors": (I, [P, I]),
     "nnet1_get_stats": (I, [P, P, P, P]),
     "nnet1_reset_stats": (I, [P]),
     "nnet1_write": (I, [P, ctypes.c_char_p, I]),
@@ -76,6 +77,10 @@ class Trainer:
 
     def train_bunch(self, feats_ptr, ld, rows, cols, labels_ptr, cross_validate=False):
         _check(lib.nnet1_train_bunch(self.h, feats_ptr, ld, rows, cols, labels_ptr, int(cross_validate)))
+
+    def keep_posteriors(self, keep):
+        """False: training steps do not write the posteriors (nothing reads them in a training loop)"""
+        _check(lib.nnet1_keep_posteriors(self.h, int(keep)))
 
     def feedforward(self, feats, out):
         """feats, out: hip.DevMatrix"""

@@ -475,6 +475,43 @@ def test_affine_forward_backward_update(hip, N, O_, I):
                 np.testing.assert_allclose(bcorr.numpy()[0], layer.b_corr, rtol=1e-4, atol=1e-7)
 
 
+@pytest.mark.parametrize("N,O_,I", [(256, 1483, 1024), (256, 9000, 2048), (37, 50, 24), (64, 12000, 128)])
+def test_affine_forward_xent_equals_two_calls(hip, N, O_, I):
+    """The fused output layer (GEMM + softmax + Xent::EvalVec) against hipF_affine_forward(softmax) followed by
+    hipF_xent_eval: identical diff, arg-max ids, counters and loss; the last shape is too wide for the
+    register-resident kernel and takes the two-kernel form inside the library."""
+    h = hip
+    rs = np.random.RandomState(60)
+    x, W, b = rnd((N, I), 61), rnd((O_, I), 62, 0.1), rnd((O_,), 63, 0.5)
+    tgt = rs.randint(0, O_, N).astype(np.int32)
+    dx, dW, db, dt = dev(h, x), dev(h, W), dev(h, b, False), dev(h, tgt, False)
+    post_a, diff_a = dev(h, np.zeros((N, O_), f32)), dev(h, np.zeros((N, O_), f32))
+    cnt_a, loss_a = h.DevMatrix(1, 2, np.int64, pitched=False), h.DevMatrix(1, 1, np.float64, pitched=False)
+    mid_a, lp_a = h.DevMatrix(1, N, np.int32, pitched=False), h.DevMatrix(1, N, f32, pitched=False)
+    h.call("hipF_affine_forward", None, h.ACT_SOFTMAX, h.TRANS, N, O_, I, dx.ptr, dx.stride, dW.ptr, dW.stride, db.ptr,
+           post_a.ptr, post_a.stride)
+    h.call("hipF_xent_eval", None, post_a.ptr, dt.ptr, diff_a.ptr, lp_a.ptr, mid_a.ptr, cnt_a.ptr, loss_a.ptr, post_a.dim)
+    for write_post, with_rows in [(1, True), (0, False)]:
+        post_b, diff_b = dev(h, np.full((N, O_), np.nan, f32)), dev(h, np.full((N, O_), np.nan, f32))
+        cnt_b, loss_b = h.DevMatrix(1, 2, np.int64, pitched=False), h.DevMatrix(1, 1, np.float64, pitched=False)
+        mid_b, lp_b = h.DevMatrix(1, N, np.int32, pitched=False), h.DevMatrix(1, N, f32, pitched=False)
+        for _ in range(2):   # two calls accumulate
+            h.call("hipF_affine_forward_xent", None, h.TRANS, N, O_, I, dx.ptr, dx.stride, dW.ptr, dW.stride, db.ptr,
+                   post_b.ptr, post_b.stride, write_post, dt.ptr, diff_b.ptr, diff_b.stride,
+                   lp_b.ptr if with_rows else None, mid_b.ptr if with_rows else None, cnt_b.ptr, loss_b.ptr)
+        assert (diff_b.numpy() == diff_a.numpy()).all()
+        assert cnt_b.numpy()[0].tolist() == (2 * cnt_a.numpy()[0]).tolist()
+        assert abs(loss_b.numpy()[0, 0] - 2 * loss_a.numpy()[0, 0]) <= 1e-12 * abs(loss_a.numpy()[0, 0])
+        if with_rows:
+            assert (mid_b.numpy() == mid_a.numpy()).all() and (lp_b.numpy() == lp_a.numpy()).all()
+        if write_post:
+            assert (post_b.numpy() == post_a.numpy()).all()
+    # and against the oracle: exact frame-accuracy count, loss within 1e-5
+    xo = O.Xent()
+    xo.eval_vec(O.softmax(O.BiasedLinearity(W, b).propagate(x)), tgt)
+    assert int(cnt_a.numpy()[0, 1]) == N and abs(loss_a.numpy()[0, 0] - xo.loss) <= 1e-5 * abs(xo.loss)
+
+
 @pytest.mark.parametrize("V,H,vt,ht", [(440, 2048, "gauss", "bern"), (2048, 2048, "bern", "bern"), (24, 32, "bern", "gauss")])
 def test_rbm_cd1(hip, V, H, vt, ht):
     h = hip
