@@ -204,6 +204,11 @@ def main():
             trainer.keep_posteriors(False)   # like the tool: only the loss and its gradient leave the output layer
             if world > 1:
                 trainer.set_data_parallel(world)
+            elif os.environ.get("KALDI_BENCH_LOOPBACK_DP"):
+                # rehearsal of the data-parallel step on one GPU: gradient GEMM, (local) all-reduce, shared step
+                n = int(os.environ["KALDI_BENCH_LOOPBACK_DP"])
+                h.call("hipK_comm_init_loopback", n)
+                trainer.set_data_parallel(n)
         # a synthetic, already shuffled frame cache resident in HBM (each rank its own frames)
         cache_rows = 16 * BUNCH
         x = rs.standard_normal((cache_rows, dims[0])) if wl.get("types", ("gauss",))[0] == "gauss" else rs.random_sample((cache_rows, dims[0]))

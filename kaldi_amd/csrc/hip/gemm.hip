@@ -791,7 +791,13 @@ Plan make_plan(int M, int N, int K, int num_cu, bool allow_split, bool always_sl
       // with two or more workgroups on every CU one's stalls are filled by another's MFMAs
       static const double share_f = getenv("KALDI_HIP_GEMM_SHARE") ? atof(getenv("KALDI_HIP_GEMM_SHARE")) : 1.0;
       const double share = blocks >= 2.0 * num_cu ? share_f : 1.0;
-      double cost = (n * per_block * share + t.fixed) / cyc_per_us;
+      // The fixed part of a workgroup (prologue, last tile, epilogue) hides behind the K loops of the
+      // workgroups that share its CU, but only one of every `co` (how many fit a CU) stays exposed:
+      // short-K products with many small tiles (the data-parallel gradient GEMMs) pay it many times.
+      const double co = floor(163840.0 / t.lds_bytes) < floor(512.0 / t.vgprs) ? floor(163840.0 / t.lds_bytes)
+                                                                                 : floor(512.0 / t.vgprs);
+      const double rounds = n / (co > 1.0 ? co : 1.0);
+      double cost = (n * per_block * share + (rounds > 1.0 ? rounds : 1.0) * t.fixed) / cyc_per_us;
       if (s > 1 || always_slabs) cost += (s + 1.0) * (double)M * N * 4.0 / 3.5e6 + 2.5;
       if (cost < best_cost) {
         best_cost = cost;

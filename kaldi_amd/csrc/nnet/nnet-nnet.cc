@@ -14,6 +14,12 @@ namespace kaldi {
 Nnet::~Nnet() {
   for (size_t i = 0; i < nnet_.size(); ++i) delete nnet_[i];
   if (dp_grad_) hipK_free(dp_grad_);
+  for (size_t i = 0; i < dp_layer_grad_.size(); ++i)
+    if (dp_layer_grad_[i]) hipK_free(dp_layer_grad_[i]);
+  for (size_t i = 0; i < grad_events_.size(); ++i)
+    if (grad_events_[i]) hipK_event_destroy(grad_events_[i]);
+  for (size_t i = 0; i < read_events_.size(); ++i)
+    if (read_events_[i]) hipK_event_destroy(read_events_[i]);
   for (size_t i = 0; i < layer_events_.size(); ++i)
     if (layer_events_[i]) hipK_event_destroy(layer_events_[i]);
   if (join_event_) hipK_event_destroy(join_event_);
@@ -184,12 +190,40 @@ void Nnet::Backpropagate(const CuMatrix<BaseFloat> &in_err, CuMatrix<BaseFloat> 
     side_used = true;
     BiasedLinearity *bl = (nnet_[i]->GetType() == Component::kBiasedLinearity) ? static_cast<BiasedLinearity *>(nnet_[i]) : NULL;
     if (bl != NULL && dp_ranks_ > 1) {
-      // gradient and its all-reduce beside the backward pass; the step itself rewrites the
-      // weights in place, so it waits for this layer's back-propagation
-      CuStreamScope scope(dev.SideStream());
-      DataParallelGradient(i, bl, input, err);
-      dev.Order(dev.MainStream(), dev.SideStream(), &layer_events_[i]);
-      bl->ApplyGradient(dp_grad_, input.NumRows() * dp_ranks_);
+      // Three queues: the gradient GEMMs follow one another on the side stream, each layer's
+      // all-reduce and shared step go to the third stream, so that communication of layer i runs
+      // beside the gradient GEMMs and back-propagation of the layers below (a buffer per layer:
+      // the next GEMM must not overwrite a gradient that is still being reduced).  The step
+      // rewrites the weights in place, so it also waits for this layer's back-propagation.
+      if (static_cast<int32>(dp_layer_grad_.size()) < L) {
+        dp_layer_grad_.resize(L, NULL);
+        dp_layer_grad_size_.resize(L, 0);
+        grad_events_.resize(L, NULL);
+        read_events_.resize(L, NULL);
+      }
+      const size_t need = bl->GradientSize();
+      if (need > dp_layer_grad_size_[i]) {
+        if (dp_layer_grad_[i]) {
+          CU_SAFE_CALL(hipK_device_synchronize());
+          CU_SAFE_CALL(hipK_free(dp_layer_grad_[i]));
+        }
+        void *p = NULL;
+        CU_SAFE_CALL(hipK_malloc(&p, need * sizeof(BaseFloat)));
+        dp_layer_grad_[i] = static_cast<BaseFloat *>(p);
+        dp_layer_grad_size_[i] = need;
+      }
+      {
+        CuStreamScope scope(dev.SideStream());
+        bl->ComputeGradient(input, err, dp_layer_grad_[i]);
+      }
+      dev.Order(dev.SideStream(), dev.AuxStream(), &grad_events_[i]);
+      dev.Order(dev.MainStream(), dev.AuxStream(), &read_events_[i]);
+      {
+        CuStreamScope scope(dev.AuxStream());
+        CU_SAFE_CALL(hipF_allreduce_sum(dev.AuxStream(), dp_layer_grad_[i], need));
+        bl->ApplyGradient(dp_layer_grad_[i], input.NumRows() * dp_ranks_);
+      }
+      aux_used = true;
       return;
     }
     if (bl != NULL && bl->UpdateKeepsOldWeights()) {

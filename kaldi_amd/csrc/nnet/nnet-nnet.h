@@ -98,6 +98,10 @@ class Nnet {
   BaseFloat *dp_grad_;   // device staging buffer for one layer's gradient
   size_t dp_grad_size_;
   std::vector<khEvent_t> layer_events_;  // "error of layer i ready, its weights no longer read"
+  std::vector<khEvent_t> grad_events_;   // data-parallel: "local gradient of layer i complete"
+  std::vector<khEvent_t> read_events_;   // data-parallel: "back-propagation of layer i has read its weights"
+  std::vector<BaseFloat *> dp_layer_grad_;  // data-parallel: one gradient buffer per layer
+  std::vector<size_t> dp_layer_grad_size_;
   khEvent_t join_event_, aux_join_event_;
   KALDI_DISALLOW_COPY_AND_ASSIGN(Nnet);
 };

@@ -16,8 +16,8 @@ def short(n):
     return n.split("(")[0][:40]
 
 
-# one step = from one xent_rows_kernel to the next
-idx = [i for i, r in enumerate(rows) if "xent_rows" in r["Kernel_Name"]]
+# one step = from one loss kernel to the next
+idx = [i for i, r in enumerate(rows) if "xent_rows" in r["Kernel_Name"] or "softmax_xent" in r["Kernel_Name"]]
 a, b = idx[-3], idx[-2]
 # start the step at the first kernel after the previous step's last update
 step = rows[a:b]
