@@ -72,7 +72,7 @@ def gen_dnn_steps(tmp):
     cfgs = {
         "plain": dict(nsteps=2, lr=0.008, mom=0.0, l2=0.0, l1=0.0, l2ub=0.0, avg=0),
         # no --l2-penalty anywhere: the reference's CPU branch aborts on it (self-AddMat is taken
-        # as a transposed add, matrix/kaldi-matrix.cc:275-281), see DESIGN.md
+        # as a transposed add and trips its assert on a non-square matrix, matrix/kaldi-matrix.cc:275-281)
         "mom_avg": dict(nsteps=3, lr=0.5, mom=0.9, l2=0.0, l1=0.0, l2ub=0.0, avg=1),
         "l1": dict(nsteps=2, lr=0.05, mom=0.5, l2=0.0, l1=2e-3, l2ub=0.0, avg=0),
         "l2ub": dict(nsteps=2, lr=0.5, mom=0.0, l2=0.0, l1=0.0, l2ub=0.4, avg=0),
@@ -212,7 +212,8 @@ def gen_rbm(tmp):
         np.savez_compressed(os.path.join(HERE, "rbm_small_%s.npz" % name), **fix)
         print("rbm_small_%s: %d arrays" % (name, len(fix)))
     # the reference tool end to end (gaussian hidden units work on its CPU path; bernoulli hidden
-    # units abort there): shuffle + sampling both draw from rand()
+    # units abort there: BinarizeProbs never sizes its state matrix, cu-rand-inl.h:162-168): shuffle + sampling
+    # both draw from rand()
     rs = np.random.RandomState(100)
     V, H = 24, 32
     rbm = O.Rbm((0.1 * rs.randn(H, V)).astype(f32), np.zeros(V, f32), np.zeros(H, f32), "bern", "gauss")
