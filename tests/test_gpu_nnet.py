@@ -261,6 +261,62 @@ def test_nnet_copy_and_rbm_convert_tools(hip, nn, tmp_path):
         assert (tmp_path / "r.txt").read_bytes() == g["rbm_%s_nnet_txt" % name].tobytes()
 
 
+def test_recipe_scheduler_contract(hip, nn, tmp_path):
+    """The way the recipes drive the trainer (egs/aurora4/a00/steps/nnet_scheduler/train_scheduler.sh:76-160):
+    a cross-validation pre-run, then per iteration a training run and a cross-validation run with exactly
+    the options the script passes, stderr appended to a log, the accuracy taken from the log with awk
+    ($3 of the FRAME_ACCURACY line, '%' stripped), the new network kept if it improved, the learning
+    rate halved when the improvement is small.  On a learnable synthetic task the loop must accept
+    networks and the held-out accuracy must rise."""
+    rs = np.random.RandomState(5)
+    dims = [24, 48, 10]
+    proj = rs.randn(dims[0], dims[-1]).astype(f32)
+
+    def make_set(n_utts, seed):
+        r = np.random.RandomState(seed)
+        utts, alis = [], []
+        for i in range(n_utts):
+            x = r.randn(int(r.randint(40, 120)), dims[0]).astype(f32)
+            utts.append(("u%03d" % i, x))
+            alis.append(("u%03d" % i, np.argmax(x @ proj, axis=1).astype(np.int32)))
+        return O.write_matrix_ark(utts), O.write_int32_vector_ark(alis, binary=False)
+
+    for name, n, seed in (("tr", 40, 1), ("cv", 10, 2)):
+        f, a = make_set(n, seed)
+        (tmp_path / (name + ".ark")).write_bytes(f)
+        (tmp_path / (name + ".ali")).write_bytes(a)
+    layers = [O.BiasedLinearity((0.1 * rs.randn(dims[1], dims[0])).astype(f32), np.zeros(dims[1], f32)), O.Sigmoid(dims[1]),
+              O.BiasedLinearity((0.1 * rs.randn(dims[2], dims[1])).astype(f32), np.zeros(dims[2], f32)), O.Softmax(dims[2])]
+    (tmp_path / "0.nnet").write_bytes(O.write_nnet(layers, True))
+    exe = os.path.join(nn.BIN_DIR, "nnet-train-xent-hardlab-frmshuff")
+
+    def run(args, log):
+        with open(log, "ab") as lf:
+            assert subprocess.run([exe] + args, stderr=lf, stdout=subprocess.DEVNULL, timeout=100).returncode == 0
+        out = subprocess.run(["awk", '/FRAME_ACCURACY/{ acc=$3; sub(/%/,"",acc); } END{print acc}', log],
+                             stdout=subprocess.PIPE).stdout.decode().strip()
+        return float(out)
+
+    common = ["--bunchsize=64", "--cachesize=1024", "--verbose=1"]
+    best, lr = str(tmp_path / "0.nnet"), 0.5
+    acc = run(["--cross-validate=true"] + common + ["ark:" + str(tmp_path / "cv.ark"), "ark:" + str(tmp_path / "cv.ali"), best],
+              str(tmp_path / "iter00.initial.log"))
+    first, accepted = acc, 0
+    for it in range(1, 6):
+        nxt = str(tmp_path / ("iter%02d.nnet" % it))
+        run(["--learn-rate=%g" % lr, "--momentum=0", "--l1-penalty=0", "--l2-penalty=0"] + common +
+            ["--randomize=true", "--binary=true", "ark:" + str(tmp_path / "tr.ark"), "ark:" + str(tmp_path / "tr.ali"), best, nxt],
+            str(tmp_path / ("iter%02d.tr.log" % it)))
+        acc_new = run(["--cross-validate=true"] + common + ["ark:" + str(tmp_path / "cv.ark"), "ark:" + str(tmp_path / "cv.ali"), nxt],
+                      str(tmp_path / ("iter%02d.cv.log" % it)))
+        prev = acc
+        if acc_new > acc:
+            acc, best, accepted = acc_new, nxt, accepted + 1
+        if acc < prev + 0.5:
+            lr *= 0.5
+    assert accepted >= 2 and acc > first + 20.0, (first, acc, accepted)
+
+
 def test_train_tool_text_model_and_usage(hip, nn, tmp_path):
     g = load("train_e2e_small.npz")
     (tmp_path / "m.nnet").write_bytes(g["model"].tobytes())
