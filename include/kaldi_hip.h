@@ -331,6 +331,16 @@ int hipF_rbm_update(khStream_t s, int32_t N, int32_t H, int32_t V, const float *
                     const float *neg_hid, int32_t ldnh, float lr, float momentum, float l2, float *W,
                     int32_t ldw, float *dW, int32_t lddw, float *vis_bias, float *dvis_bias,
                     float *hid_bias, float *dhid_bias);
+/* The two halves of hipF_rbm_update, for callers that queue them on different streams (the bias half only
+ * reads the four activation matrices, so it can run beside the two statistic GEMMs of the weight half). */
+int hipF_rbm_update_weights(khStream_t s, int32_t N, int32_t H, int32_t V, const float *pos_vis, int32_t ldpv,
+                            const float *pos_hid, int32_t ldph, const float *neg_vis, int32_t ldnv,
+                            const float *neg_hid, int32_t ldnh, float lr, float momentum, float l2, float *W,
+                            int32_t ldw, float *dW, int32_t lddw);
+int hipF_rbm_update_bias(khStream_t s, int32_t N, int32_t H, int32_t V, const float *pos_vis, int32_t ldpv,
+                         const float *pos_hid, int32_t ldph, const float *neg_vis, int32_t ldnv,
+                         const float *neg_hid, int32_t ldnh, float lr, float momentum, float *vis_bias,
+                         float *dvis_bias, float *hid_bias, float *dhid_bias);
 
 /* ------------------------------------------------------------------------------------------
  * Multi-GPU (no counterpart in the reference, which is single-GPU: cu-device.cc).

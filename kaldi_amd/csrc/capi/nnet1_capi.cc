@@ -27,6 +27,7 @@ struct RbmTrainer {
   CuRand<BaseFloat> cu_rand;
   MseProgress mse;
   CuMatrix<BaseFloat> pos_vis, pos_hid, neg_vis, neg_hid, dummy;
+  khEvent_t mse_start = NULL, mse_done = NULL;
 };
 
 // device rows (ld) -> CuMatrix, the copy Cache::GetBunch makes
@@ -210,7 +211,8 @@ int rbm1_cd1_bunch(void *h, const float *feats_dev, int ld, int rows, int cols) 
   CAPI_TRY
   RbmTrainer *t = static_cast<RbmTrainer *>(h);
   RbmBase &rbm = dynamic_cast<RbmBase &>(*t->nnet.Layer(0));
-  CopyIn(feats_dev, ld, rows, cols, &t->pos_vis);
+  // a window onto the caller's rows (read-only here), like a bunch taken out of the cache
+  t->pos_vis.AttachView(const_cast<float *>(feats_dev), rows, cols, ld);
   rbm.Propagate(t->pos_vis, &t->pos_hid);
   if (rbm.HidType() == Rbm::BERNOULLI) {
     t->cu_rand.BinarizeProbs(t->pos_hid, &t->neg_hid);
@@ -219,9 +221,16 @@ int rbm1_cd1_bunch(void *h, const float *feats_dev, int ld, int rows, int cols) 
     t->cu_rand.AddGaussNoise(&t->neg_hid);
   }
   rbm.Reconstruct(t->neg_hid, &t->neg_vis);
+  CuDevice &dev = CuDevice::Instantiate();
+  {
+    // reconstruction error on the third stream beside the rest of the step (as in the tool)
+    dev.Order(dev.MainStream(), dev.AuxStream(), &t->mse_start);
+    CuStreamScope scope(dev.AuxStream());
+    t->mse.Eval(t->neg_vis, t->pos_vis, &t->dummy);
+  }
   rbm.Propagate(t->neg_vis, &t->neg_hid);
   rbm.RbmUpdate(t->pos_vis, t->pos_hid, t->neg_vis, t->neg_hid);
-  t->mse.Eval(t->neg_vis, t->pos_vis, &t->dummy);
+  dev.Order(dev.AuxStream(), dev.MainStream(), &t->mse_done);
   return 0;
   CAPI_CATCH(-1)
 }

@@ -1281,14 +1281,13 @@ KH_EXPORT int hipF_affine_update(khStream_t s, int32_t N, int32_t O, int32_t I, 
   return hipF_affine_update_bias(s, N, O, e, lde, gscale, momentum, lr, bias, bcorr);
 }
 
-KH_EXPORT int hipF_rbm_update(khStream_t s, int32_t N, int32_t H, int32_t V, const float *pos_vis, int32_t ldpv,
-                              const float *pos_hid, int32_t ldph, const float *neg_vis, int32_t ldnv,
-                              const float *neg_hid, int32_t ldnh, float lr, float momentum, float l2, float *W,
-                              int32_t ldw, float *dW, int32_t lddw, float *vis_bias, float *dvis_bias,
-                              float *hid_bias, float *dhid_bias) {
+KH_EXPORT int hipF_rbm_update_weights(khStream_t s, int32_t N, int32_t H, int32_t V, const float *pos_vis, int32_t ldpv,
+                                      const float *pos_hid, int32_t ldph, const float *neg_vis, int32_t ldnv,
+                                      const float *neg_hid, int32_t ldnh, float lr, float momentum, float l2, float *W,
+                                      int32_t ldw, float *dW, int32_t lddw) {
   KH_CHECK_INIT();
   KH_REQUIRE(N > 0 && H > 0 && V > 0);
-  KH_REQUIRE(pos_vis && pos_hid && neg_vis && neg_hid && W && dW && vis_bias && dvis_bias && hid_bias && dhid_bias);
+  KH_REQUIRE(pos_vis && pos_hid && neg_vis && neg_hid && W && dW);
   KH_REQUIRE(ldpv >= V && ldnv >= V && ldph >= H && ldnh >= H && ldw >= V && lddw >= V);
   const float g = lr / (float)N;
   // dW = -g * neg_hid^T neg_vis + mom * dW
@@ -1305,12 +1304,34 @@ KH_EXPORT int hipF_rbm_update(khStream_t s, int32_t N, int32_t H, int32_t V, con
   p2.ldw = ldw;
   p2.Wout = W;
   p2.ldwout = ldw;
-  rc = run_gemm<EPI_RBM>(s, false, false, p2, false);
-  if (rc != KH_OK) return rc;
+  return run_gemm<EPI_RBM>(s, false, false, p2, false);
+}
+
+KH_EXPORT int hipF_rbm_update_bias(khStream_t s, int32_t N, int32_t H, int32_t V, const float *pos_vis, int32_t ldpv,
+                                   const float *pos_hid, int32_t ldph, const float *neg_vis, int32_t ldnv,
+                                   const float *neg_hid, int32_t ldnh, float lr, float momentum, float *vis_bias,
+                                   float *dvis_bias, float *hid_bias, float *dhid_bias) {
+  KH_CHECK_INIT();
+  KH_REQUIRE(N > 0 && H > 0 && V > 0);
+  KH_REQUIRE(pos_vis && pos_hid && neg_vis && neg_hid && vis_bias && dvis_bias && hid_bias && dhid_bias);
+  KH_REQUIRE(ldpv >= V && ldnv >= V && ldph >= H && ldnh >= H);
+  const float g = lr / (float)N;
   hipStream_t st = kh::pick(s);
   hipLaunchKernelGGL(rbm_bias_kernel, dim3((V + 63) / 64), dim3(1024), 0, st, pos_vis, ldpv, neg_vis, ldnv, N, V, g,
                      momentum, vis_bias, dvis_bias);
   hipLaunchKernelGGL(rbm_bias_kernel, dim3((H + 63) / 64), dim3(1024), 0, st, pos_hid, ldph, neg_hid, ldnh, N, H, g,
                      momentum, hid_bias, dhid_bias);
   return kh::launch_status();
+}
+
+KH_EXPORT int hipF_rbm_update(khStream_t s, int32_t N, int32_t H, int32_t V, const float *pos_vis, int32_t ldpv,
+                              const float *pos_hid, int32_t ldph, const float *neg_vis, int32_t ldnv,
+                              const float *neg_hid, int32_t ldnh, float lr, float momentum, float l2, float *W,
+                              int32_t ldw, float *dW, int32_t lddw, float *vis_bias, float *dvis_bias,
+                              float *hid_bias, float *dhid_bias) {
+  int rc = hipF_rbm_update_weights(s, N, H, V, pos_vis, ldpv, pos_hid, ldph, neg_vis, ldnv, neg_hid, ldnh, lr, momentum, l2,
+                                   W, ldw, dW, lddw);
+  if (rc != KH_OK) return rc;
+  return hipF_rbm_update_bias(s, N, H, V, pos_vis, ldpv, pos_hid, ldph, neg_vis, ldnv, neg_hid, ldnh, lr, momentum, vis_bias,
+                              dvis_bias, hid_bias, dhid_bias);
 }
