@@ -111,23 +111,34 @@ class Timer:
         return ms.value
 
 
+class _OwnedPtr(ctypes.c_void_p):
+    """A device address that keeps the DevMatrix it came from alive: `DevMatrix(...).ptr` passed straight
+    into a call must not have its memory freed before the call is made."""
+
+
 class DevMatrix:
     """A pitched float32 (or int32 / uint32 / double / int64) device buffer with host<->device copies.
     Owns its memory.  Test/bench plumbing only."""
 
     def __init__(self, rows, cols, dtype=np.float32, pitched=True, zero=True):
         self.rows, self.cols, self.dtype = int(rows), int(cols), np.dtype(dtype)
-        self.ptr = ctypes.c_void_p()
+        self._p = ctypes.c_void_p()
         es = self.dtype.itemsize
         if pitched and es in (4, 8):
             st = ctypes.c_int32()
-            call("hipK_malloc_pitch", ctypes.byref(self.ptr), ctypes.byref(st), self.rows, self.cols, es)
+            call("hipK_malloc_pitch", ctypes.byref(self._p), ctypes.byref(st), self.rows, self.cols, es)
             self.stride = st.value
         else:
             self.stride = self.cols
-            call("hipK_malloc", ctypes.byref(self.ptr), self.rows * self.cols * es)
+            call("hipK_malloc", ctypes.byref(self._p), self.rows * self.cols * es)
         if zero and self.nbytes:
             call("hipK_memset_async", None, self.ptr, 0, self.nbytes)
+
+    @property
+    def ptr(self):
+        p = _OwnedPtr(self._p.value)
+        p._owner = self
+        return p
 
     @property
     def nbytes(self):
@@ -164,9 +175,9 @@ class DevMatrix:
         return out
 
     def free(self):
-        if self.ptr:
-            lib.hipK_free(self.ptr)
-            self.ptr = ctypes.c_void_p()
+        if self._p:
+            lib.hipK_free(self._p)
+            self._p = ctypes.c_void_p()
 
     def __del__(self):
         try:
