@@ -5,10 +5,13 @@
 // nnet/nnet-activation.h:207-218, nnet/nnet-rbm.h:136-223).
 //
 // Shape of the problem on this path: M = minibatch (256) for forward/backward, so a plain
-// one-tile-per-block decomposition leaves most of the 256 CUs idle.  The K dimension is
-// therefore split over workgroups (split-K); each split writes an fp32 partial slab and the
-// element-wise kernel that has to run next anyway (bias + sigmoid, softmax, y(1-y) scaling,
-// alpha/beta) sums the slabs in a fixed order -- no atomics, bit-reproducible.
+// one-64x64-tile-per-workgroup decomposition leaves most of the 256 CUs idle.  Two ways out, both
+// here: small tiles (32x64, 32x32) whose four waves split K among themselves and add their
+// accumulators through LDS before the epilogue (a 256 x 2048 product is then 256 workgroups and
+// finishes its elements -- bias + sigmoid, y(1-y) -- in the same kernel); and K split over
+// workgroups, each writing an fp32 partial slab that the element-wise kernel which has to run
+// next anyway (softmax, y(1-y) scaling, alpha/beta) sums in a fixed order.  No atomics either
+// way: results are bit-reproducible.
 //
 // Kernel structure (one workgroup = 4 waves = 256 threads, one output tile BM x BN):
 //   global --dwordx4--> VGPR (next K-tile, issued before the MFMAs of the current one)
@@ -741,16 +744,17 @@ struct Plan {
   int k_per_split;
 };
 
-// Picks the tile and the K split.  Measured on the hot-path shapes (M = 256 rows; 440..9000
-// columns and depth), the 64x64 tile is within 2 % of the best tile everywhere and clearly best
-// for the weight-update GEMMs, so the larger tiles are only used when forced (experiments).
-// What is left is the split, chosen with a small cycle model of the 64x64 kernel: a workgroup
-// pulls its operand tiles through L2 at the ~12.5 B/clk a CU sustains for this access pattern
-// (that, not the MFMA rate, bounds a 64x64 tile), the busiest CU runs ceil(workgroups / CUs) of
-// them, the fixed part of a workgroup (prologue, last tile, epilogue: ~4400 cycles by in-kernel
-// stamps) is paid once because co-resident workgroups cover each other's, and a split K adds the
-// slab round trip plus the launch of the kernel that sums the slabs.  The picks were checked
-// against a sweep over every tile / split for the Switchboard- and RM-sized layers.
+// Picks the tile and the K split with a small cycle model of the kernel, checked against sweeps over
+// every tile / split for the Switchboard- and RM-sized layers (tools/gemm_sweep.py).  Candidates: the
+// 64x64 tile (within 2 % of the best of the large tiles everywhere, clearly best for the
+// weight-update GEMMs; the larger ones only when forced) and, where the epilogue allows it, the
+// two tiles whose waves split K.  Model: the busiest CU runs ceil(workgroups / CUs) workgroups one
+// after another; a workgroup costs its MFMAs x 1.28 (what the 64x64 kernel measures against the
+// bare MFMA count; for that tile written as the ~12.5 B/clk of operand staging a CU sustained in
+// the first version of the kernel); its fixed part (prologue, last tile, epilogue: ~4400 cycles by
+// in-kernel stamps) hides behind the K loops of the workgroups that share the CU, so it is exposed
+// once per round of co-resident workgroups; a split K adds the slab round trip and the launch of
+// the kernel that sums the slabs.
 int force_bm = -1, force_bn = -1, force_s = -1;
 bool env_read = false;
 
