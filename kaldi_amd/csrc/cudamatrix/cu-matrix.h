@@ -162,7 +162,7 @@ class CuMatrix {
     return *this;
   }
   void CopyToMat(Matrix<Real> *dst) const {
-    if (dst->NumRows() != num_rows_ || dst->NumCols() != num_cols_) dst->Resize(num_rows_, num_cols_);
+    if (dst->NumRows() != num_rows_ || dst->NumCols() != num_cols_) dst->Resize(num_rows_, num_cols_, kUndefined);
     Copy2D(dst->Data(), dst->Stride(), data_, stride_, num_cols_, num_rows_, 1);
   }
   /// this <- src[ro:ro+r, co:co+c]; this must already be r x c

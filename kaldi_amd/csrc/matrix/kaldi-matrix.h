@@ -30,12 +30,15 @@ class Matrix {
   Real &operator()(MatrixIndexT r, MatrixIndexT c) { return data_[static_cast<size_t>(r) * cols_ + c]; }
   Real operator()(MatrixIndexT r, MatrixIndexT c) const { return data_[static_cast<size_t>(r) * cols_ + c]; }
 
-  void Resize(MatrixIndexT r, MatrixIndexT c, MatrixResizeType = kSetZero) {
+  /// kSetZero: all zero afterwards; kUndefined: contents unspecified (for buffers about to be
+  /// overwritten whole: no pass over the memory when the allocation is already large enough)
+  void Resize(MatrixIndexT r, MatrixIndexT c, MatrixResizeType type = kSetZero) {
     KALDI_ASSERT(r >= 0 && c >= 0);
     if (r == 0 || c == 0) r = c = 0;
     rows_ = r;
     cols_ = c;
-    data_.assign(static_cast<size_t>(r) * c, Real(0));
+    if (type == kUndefined) data_.resize(static_cast<size_t>(r) * c);
+    else data_.assign(static_cast<size_t>(r) * c, Real(0));
   }
   void SetZero() { data_.assign(data_.size(), Real(0)); }
   void SetUnit() {

@@ -71,10 +71,11 @@ int main(int argc, char *argv[]) {
 
     kaldi::int64 tot_t = 0;
     PrefetchingBaseFloatMatrixReader feature_reader(feature_rspecifier);  // reads ahead on a thread of its own
-    BaseFloatMatrixWriter feature_writer(feature_wspecifier);
+    // writes behind on a thread of its own, which also scans every output for NaN / inf first
+    AsyncBaseFloatMatrixWriter feature_writer(
+        feature_wspecifier, 3, [](const std::string &key, const Matrix<BaseFloat> &m) { CheckFinite(m, "NNet output", key); });
 
     CuMatrix<BaseFloat> feats, feats_transf, nnet_out;
-    Matrix<BaseFloat> nnet_out_host;
 
     // class priors from frame counts: log-domain offset or linear-domain scale
     Vector<BaseFloat> tmp_priors;
@@ -111,14 +112,15 @@ int main(int argc, char *argv[]) {
         if (apply_log || no_softmax) nnet_out.AddVecToRows(1.0, priors, 1.0);
         else nnet_out.MulColsVec(priors);
       }
-      nnet_out.CopyToMat(&nnet_out_host);
-      CheckFinite(nnet_out_host, "NNet output", feature_reader.Key());
-      feature_writer.Write(feature_reader.Key(), nnet_out_host);
+      Matrix<BaseFloat> *nnet_out_host = feature_writer.Acquire();
+      nnet_out.CopyToMat(nnet_out_host);
+      feature_writer.Submit(feature_reader.Key(), nnet_out_host);
       if (num_done % 1000 == 0 && !silent) KALDI_LOG << num_done << ", " << std::flush;
       num_done++;
       tot_t += mat.NumRows();
     }
 
+    if (!feature_writer.Close()) KALDI_ERR << "Error closing the output table " << feature_wspecifier;
     if (!silent) KALDI_LOG << "MLP FEEDFORWARD FINISHED " << tim.Elapsed() << "s, fps" << tot_t / tim.Elapsed();
     if (!silent) KALDI_LOG << "Done " << num_done << " files";
     if (!silent) CuDevice::Instantiate().PrintProfile();

@@ -8,6 +8,7 @@
 #include <condition_variable>
 #include <deque>
 #include <exception>
+#include <functional>
 #include <memory>
 #include <mutex>
 #include <thread>
@@ -412,6 +413,103 @@ class TableWriter {
   Output archive_, script_;
   std::unordered_map<std::string, std::string> script_map_;
   KALDI_DISALLOW_COPY_AND_ASSIGN(TableWriter);
+};
+
+// ---- writer with a write-behind thread ------------------------------------------------------
+// The caller fills one of a few reusable value buffers (Acquire), hands it over with its key
+// (Submit) and goes on; a background thread serialises the values into the table in submission
+// order and returns the buffers.  nnet-forward spends most of its time formatting and writing
+// posteriors (nnetbin/nnet-forward.cc:151-160): this takes that off the thread that drives the
+// GPU.  An error raised while writing surfaces at the next Acquire / Close.  Not in the reference.
+template <class Holder>
+class AsyncTableWriter {
+ public:
+  typedef typename Holder::T T;
+  typedef std::function<void(const std::string &, const T &)> Check;
+  /// `before_write` (optional) runs on the writer thread for every value before it is written, e.g. a
+  /// validity check that throws
+  explicit AsyncTableWriter(const std::string &wspecifier, size_t num_buffers = 3, Check before_write = Check())
+      : writer_(wspecifier), buffers_(num_buffers), before_write_(before_write), stop_(false) {
+    for (size_t i = 0; i < buffers_.size(); ++i) free_.push_back(&buffers_[i]);
+    thread_ = std::thread(&AsyncTableWriter::Run, this);
+  }
+  ~AsyncTableWriter() {
+    try {
+      Close();
+    } catch (...) {
+    }
+  }
+  /// a buffer nobody else is using (waits for the writer thread if all are queued)
+  T *Acquire() {
+    std::unique_lock<std::mutex> l(mu_);
+    cv_free_.wait(l, [this] { return !free_.empty() || error_; });
+    Rethrow();
+    T *b = free_.back();
+    free_.pop_back();
+    return b;
+  }
+  void Submit(const std::string &key, T *value) {
+    std::lock_guard<std::mutex> l(mu_);
+    queue_.push_back(std::make_pair(key, value));
+    cv_work_.notify_one();
+  }
+  /// writes everything submitted so far, stops the thread and closes the table
+  bool Close() {
+    if (thread_.joinable()) {
+      {
+        std::lock_guard<std::mutex> l(mu_);
+        stop_ = true;
+      }
+      cv_work_.notify_all();
+      thread_.join();
+    }
+    {
+      std::lock_guard<std::mutex> l(mu_);
+      Rethrow();
+    }
+    return writer_.IsOpen() ? writer_.Close() : true;
+  }
+
+ private:
+  void Rethrow() {
+    if (error_) {
+      std::exception_ptr e = error_;
+      error_ = nullptr;
+      std::rethrow_exception(e);
+    }
+  }
+  void Run() {
+    for (;;) {
+      std::pair<std::string, T *> item;
+      {
+        std::unique_lock<std::mutex> l(mu_);
+        cv_work_.wait(l, [this] { return !queue_.empty() || stop_; });
+        if (queue_.empty()) return;
+        item = queue_.front();
+        queue_.pop_front();
+      }
+      try {
+        if (before_write_) before_write_(item.first, *item.second);
+        writer_.Write(item.first, *item.second);
+      } catch (...) {
+        std::lock_guard<std::mutex> l(mu_);
+        if (!error_) error_ = std::current_exception();
+      }
+      std::lock_guard<std::mutex> l(mu_);
+      free_.push_back(item.second);
+      cv_free_.notify_one();
+    }
+  }
+  TableWriter<Holder> writer_;
+  std::vector<T> buffers_;
+  Check before_write_;
+  std::vector<T *> free_;
+  std::deque<std::pair<std::string, T *> > queue_;
+  std::thread thread_;
+  std::mutex mu_;
+  std::condition_variable cv_work_, cv_free_;
+  std::exception_ptr error_;
+  bool stop_;
 };
 
 }  // namespace kaldi

@@ -9,6 +9,7 @@ typedef TableWriter<KaldiObjectHolder<Matrix<BaseFloat> > > BaseFloatMatrixWrite
 typedef SequentialTableReader<KaldiObjectHolder<Matrix<BaseFloat> > > SequentialBaseFloatMatrixReader;
 typedef RandomAccessTableReader<KaldiObjectHolder<Matrix<BaseFloat> > > RandomAccessBaseFloatMatrixReader;
 typedef PrefetchingTableReader<KaldiObjectHolder<Matrix<BaseFloat> > > PrefetchingBaseFloatMatrixReader;
+typedef AsyncTableWriter<KaldiObjectHolder<Matrix<BaseFloat> > > AsyncBaseFloatMatrixWriter;
 typedef TableWriter<KaldiObjectHolder<Vector<BaseFloat> > > BaseFloatVectorWriter;
 typedef SequentialTableReader<KaldiObjectHolder<Vector<BaseFloat> > > SequentialBaseFloatVectorReader;
 typedef RandomAccessTableReader<KaldiObjectHolder<Vector<BaseFloat> > > RandomAccessBaseFloatVectorReader;
