@@ -156,8 +156,11 @@ def main():
     import torch  # plumbing only: rendezvous, barrier, max-over-ranks
     import torch.distributed as dist
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    rehearse_pg = world == 1 and os.environ.get("KALDI_BENCH_FORCE_PG") and "MASTER_ADDR" in os.environ
+    if world > 1 or rehearse_pg:
+        # (KALDI_BENCH_FORCE_PG: a one-rank group, to rehearse torch's RCCL streams beside the library's on one GPU)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        dist.barrier()
 
     from kaldi_amd import hip as h
     from kaldi_amd import nnet as nn
@@ -308,7 +311,10 @@ def main():
     trainer.close()
     if world > 1 and kind == "train":
         h.call("hipK_comm_destroy")
-    if world > 1:
+    if rehearse_pg:
+        t_el = torch.ones(4, device="cuda")
+        dist.all_reduce(t_el)
+    if world > 1 or rehearse_pg:
         dist.barrier()
         dist.destroy_process_group()
     for f in os.listdir(tmp):

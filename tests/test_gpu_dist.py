@@ -98,3 +98,16 @@ def test_forward_sharded_over_two_ranks_equals_single(hip, nn, tmp_path):
     for i, (k, _) in enumerate(utts):
         assert k in shards[want[i]]                                    # the documented rule
         np.testing.assert_array_equal(shards[want[i]][k], single[k])   # same kernels, same rows: bit for bit
+
+
+@pytest.mark.parametrize("mode", ["alone", "torch"])
+def test_rccl_communicator_single_rank(hip, mode):
+    """The real RCCL path of the device library (unique id, ncclCommInitRank, sum / min all-reduce, barrier,
+    destroy) with one rank, in a process of its own; "torch": after torch has loaded its own RCCL and opened
+    a process group, as bench.py does when launched with several ranks."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "tools", "rccl_probe.py")] + (["torch"] if mode == "torch" else [])
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29547")
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=110, env=env)
+    assert r.returncode == 0 and b"rccl probe ok" in r.stdout, r.stderr.decode()[-2000:]
