@@ -51,7 +51,10 @@ __global__ __launch_bounds__(256) void row_sums_kernel(float alpha, const float 
 // One block per row.  The row is staged in LDS while its maximum is found, exponentiated in
 // place while the sum is formed, then scaled on the way out: x is read once, y written once.
 // Rows longer than the LDS staging buffer re-read x from L2 instead.
-constexpr int kSoftmaxThreads = 512;
+#ifndef KH_SOFTMAX_THREADS
+#define KH_SOFTMAX_THREADS 512
+#endif
+constexpr int kSoftmaxThreads = KH_SOFTMAX_THREADS;
 constexpr int kSoftmaxLdsFloats = 12288;  // 48 KiB: up to 3 blocks per CU
 
 // x may be given as `nslab` partial slabs (split-K GEMM output) plus a per-column bias; the
@@ -447,9 +450,9 @@ __global__ __launch_bounds__(kSoftmaxThreads) void softmax_xent_vec_kernel(float
                                                                            int nslab, size_t slab_stride,
                                                                            const float *bias, int cols, XentFuse xf) {
   __shared__ float red[16];
-  __shared__ float sv[8];
-  __shared__ int32_t si[8];
-  __shared__ float spt[8];
+  __shared__ float sv[kSoftmaxThreads / 64];
+  __shared__ int32_t si[kSoftmaxThreads / 64];
+  __shared__ float spt[kSoftmaxThreads / 64];
   const int r = blockIdx.x;
   float4 v[NV];
   const float inv = softmax_row_regs<NV>(v, x + (size_t)r * ldx, nslab, slab_stride, bias, cols, red);
@@ -571,6 +574,9 @@ int softmax_slabs_launch(hipStream_t st, float *y, int ldy, const float *x, int 
     }
     if (cols <= 4 * kSoftmaxThreads * 2)
       hipLaunchKernelGGL((softmax_xent_vec_kernel<2>), dim3(rows), dim3(kSoftmaxThreads), 0, st, y, ldy, x, ldx, nslab,
+                         slab_stride, bias, cols, xf);
+    else if (cols <= 4 * kSoftmaxThreads * 3)
+      hipLaunchKernelGGL((softmax_xent_vec_kernel<3>), dim3(rows), dim3(kSoftmaxThreads), 0, st, y, ldy, x, ldx, nslab,
                          slab_stride, bias, cols, xf);
     else
       hipLaunchKernelGGL((softmax_xent_vec_kernel<5>), dim3(rows), dim3(kSoftmaxThreads), 0, st, y, ldy, x, ldx, nslab,
