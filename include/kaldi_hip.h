@@ -22,6 +22,9 @@
  *   - only float (`hipF_`) and int32 (`hipI32_`) are provided: no file of the reference's nnet1
  *     path instantiates CuMatrix<double> (BaseFloat = float, base/kaldi-types.h:27).
  *   - arithmetic notes that matter for parity are written at each entry point.
+ *   - threading: like the reference's cudamatrix layer (one host thread, a singleton device), the
+ *     library is meant to be called from one host thread at a time; its state (default stream,
+ *     per-stream workspaces, the pinned staging buffers of the blocking copies) is not locked.
  */
 #ifndef KALDI_AMD_INCLUDE_KALDI_HIP_H_
 #define KALDI_AMD_INCLUDE_KALDI_HIP_H_
