@@ -362,6 +362,9 @@ int hipK_comm_destroy(void);
 int hipK_comm_rank(int *rank, int *nranks);
 /* in-place sum all-reduce of count floats on stream s (ordered with the kernels on s) */
 int hipF_allreduce_sum(khStream_t s, float *buf, size_t count);
+/* all-gather on stream s: every rank contributes `count` floats, recv receives nranks * count (rank r's block at
+ * r * count); send may be recv + rank * count */
+int hipF_allgather(khStream_t s, const float *send, float *recv, size_t count);
 int hipK_allreduce_sum_f64(khStream_t s, double *buf, size_t count);
 int hipK_allreduce_sum_i64(khStream_t s, long long *buf, size_t count);
 /* in-place all-reduce of count int64 with op 0 = sum, 1 = min, 2 = max (control-plane scalars:

@@ -2,6 +2,7 @@
 // counterpart (single GPU, src/cudamatrix/cu-device.cc); synchronous data-parallel training
 // sums per-layer gradients with these calls, ordered on the same stream as the kernels.
 #include <rccl/rccl.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "common.h"
@@ -20,6 +21,11 @@ __global__ void scale_kernel(T *buf, size_t n, T f) {
 Comm &comm() {
   static Comm c;
   return c;
+}
+// KALDI_HIP_COMM_FORCE_RCCL: a one-rank communicator still goes through RCCL (to exercise the calls on one GPU)
+bool force_rccl() {
+  static const bool f = getenv("KALDI_HIP_COMM_FORCE_RCCL") != nullptr;
+  return f;
 }
 int nccl_fail(ncclResult_t r, const char *what) {
   snprintf(kh::ctx().last_msg, sizeof(kh::ctx().last_msg), "%s: %s", what, ncclGetErrorString(r));
@@ -95,7 +101,7 @@ static int allreduce(khStream_t s, T *buf, size_t count, ncclDataType_t dt, nccl
   if (count == 0) return KH_OK;
   KH_REQUIRE(buf != nullptr);
   Comm &c = comm();
-  if (c.nranks == 1) return KH_OK;  // a single replica already holds the sum
+  if (c.nranks == 1 && !(force_rccl() && c.comm)) return KH_OK;  // a single replica already holds the sum
   if (c.loopback) {
     // every replica holds the same values: the sum is nranks times them, min and max are them
     if (op == ncclSum)
@@ -111,6 +117,25 @@ static int allreduce(khStream_t s, T *buf, size_t count, ncclDataType_t dt, nccl
 KH_EXPORT int hipF_allreduce_sum(khStream_t s, float *buf, size_t count) {
   return allreduce<float>(s, buf, count, ncclFloat32);
 }
+KH_EXPORT int hipF_allgather(khStream_t s, const float *send, float *recv, size_t count) {
+  KH_CHECK_INIT();
+  if (count == 0) return KH_OK;
+  KH_REQUIRE(send != nullptr && recv != nullptr);
+  Comm &c = comm();
+  hipStream_t st = kh::pick(s);
+  if (c.loopback || (c.nranks <= 1 && !(force_rccl() && c.comm))) {
+    // every replica holds this process's block
+    const int n = c.loopback ? c.nranks : 1;
+    for (int r = 0; r < n; ++r)
+      if (recv + (size_t)r * count != send)
+        KH_HIP(hipMemcpyAsync(recv + (size_t)r * count, send, count * sizeof(float), hipMemcpyDeviceToDevice, st));
+    return KH_OK;
+  }
+  if (!c.comm) return KH_ERR_NOT_INITIALISED;
+  KH_NCCL(ncclAllGather(send, recv, count, ncclFloat32, c.comm, st));
+  return KH_OK;
+}
+
 KH_EXPORT int hipK_allreduce_sum_f64(khStream_t s, double *buf, size_t count) {
   return allreduce<double>(s, buf, count, ncclFloat64);
 }

@@ -3,6 +3,8 @@
 #include "nnet/nnet-loss.h"
 
 #include <stdlib.h>
+
+#include <string>
 #include <string.h>
 
 #include "nnet/nnet-activation.h"
@@ -177,7 +179,7 @@ void Nnet::Backpropagate(const CuMatrix<BaseFloat> &in_err, CuMatrix<BaseFloat> 
     if (!overlap || !nnet_[i]->IsUpdatable()) return;
     if (nnet_[i]->GetType() != Component::kBiasedLinearity) return;
     BiasedLinearity *bl = static_cast<BiasedLinearity *>(nnet_[i]);
-    bl->SetDoubleBuffer(dp_ranks_ == 1);
+    bl->SetDoubleBuffer(dp_ranks_ == 1 || dp_gather_);
     if (bl->UpdateKeepsOldWeights() || dp_ranks_ > 1) dev.Order(dev.MainStream(), dev.SideStream(), &layer_events_[i]);
   };
   auto update = [&](int32 i, const CuMatrix<BaseFloat> &input, const CuMatrix<BaseFloat> &err) {
@@ -189,6 +191,36 @@ void Nnet::Backpropagate(const CuMatrix<BaseFloat> &in_err, CuMatrix<BaseFloat> 
     if (!(uc->GetLearnRate() > 0.0)) return;
     side_used = true;
     BiasedLinearity *bl = (nnet_[i]->GetType() == Component::kBiasedLinearity) ? static_cast<BiasedLinearity *>(nnet_[i]) : NULL;
+    if (bl != NULL && dp_ranks_ > 1 && dp_gather_) {
+      // The rows of every rank, gathered on the third stream as soon as this layer's error exists;
+      // then the ordinary fused update on all of them, on the side stream.
+      if (static_cast<int32>(dp_in_all_.size()) < L) {
+        dp_in_all_.resize(L);
+        dp_err_all_.resize(L);
+      }
+      if (static_cast<int32>(grad_events_.size()) < L) grad_events_.resize(L, NULL);
+      if (static_cast<int32>(read_events_.size()) < L) read_events_.resize(L, NULL);
+      const int32 rows = input.NumRows();
+      {
+        CuStreamScope scope(dev.AuxStream());  // (a first-time Resize zero-fills on this stream)
+        dp_in_all_[i].Resize(rows * dp_ranks_, input.NumCols());
+        dp_err_all_[i].Resize(rows * dp_ranks_, err.NumCols());
+      }
+      KALDI_ASSERT(dp_in_all_[i].Stride() == input.Stride() && dp_err_all_[i].Stride() == err.Stride());
+      CU_SAFE_CALL(hipK_stream_wait_event(dev.AuxStream(), layer_events_[i]));
+      CU_SAFE_CALL(hipF_allgather(dev.AuxStream(), input.Data(), dp_in_all_[i].Data(),
+                                  static_cast<size_t>(rows) * input.Stride()));
+      CU_SAFE_CALL(hipF_allgather(dev.AuxStream(), err.Data(), dp_err_all_[i].Data(),
+                                  static_cast<size_t>(rows) * err.Stride()));
+      dev.Order(dev.AuxStream(), dev.SideStream(), &grad_events_[i]);
+      // without a second weight buffer (L1 penalty) the step must also wait for this layer's back-propagation
+      if (!bl->UpdateKeepsOldWeights()) dev.Order(dev.MainStream(), dev.SideStream(), &read_events_[i]);
+      CuStreamScope scope(dev.SideStream());
+      bl->UpdateWeights(dp_in_all_[i], dp_err_all_[i]);
+      bl->UpdateBias(dp_err_all_[i]);
+      aux_used = true;
+      return;
+    }
     if (bl != NULL && dp_ranks_ > 1) {
       // Three queues: the gradient GEMMs follow one another on the side stream, each layer's
       // all-reduce and shared step go to the third stream, so that communication of layer i runs
@@ -389,6 +421,13 @@ void Nnet::SetAverageGrad(bool flag) { KALDI_AMD_FOR_UPDATABLE(SetAverageGrad(fl
 void Nnet::SetDataParallel(int32 nranks) {
   KALDI_ASSERT(nranks >= 1);
   dp_ranks_ = nranks;
+  // Two exchanges give the same step.  Summing the per-layer gradients moves 2(n-1)/n x 185 MB per
+  // rank and step on the Switchboard net whatever the bunch; gathering every rank's rows of (layer
+  // input, layer error) moves (n-1) x 40 MB at a 256-frame bunch, and each rank then runs the
+  // single-GPU fused update on the n x 256 gathered rows (n times the update FLOPs, no gradient
+  // buffers, replicas identical by construction).  Few ranks: gather; many: sum.
+  dp_gather_ = nranks >= 2 && nranks <= 4;
+  if (const char *e = getenv("KALDI_AMD_DP_EXCHANGE")) dp_gather_ = nranks >= 2 && std::string(e) == "gather";
 }
 
 // ---- activations that look their buffers up in the owning network ------------------------------

@@ -100,6 +100,8 @@ class Nnet {
   std::vector<khEvent_t> layer_events_;  // "error of layer i ready, its weights no longer read"
   std::vector<khEvent_t> grad_events_;   // data-parallel: "local gradient of layer i complete"
   std::vector<khEvent_t> read_events_;   // data-parallel: "back-propagation of layer i has read its weights"
+  bool dp_gather_ = false;  // data-parallel by gathering every rank's (input, error) rows instead of summing gradients
+  std::vector<CuMatrix<BaseFloat> > dp_in_all_, dp_err_all_;  // the gathered rows, per layer
   std::vector<BaseFloat *> dp_layer_grad_;  // data-parallel: one gradient buffer per layer
   std::vector<size_t> dp_layer_grad_size_;
   khEvent_t join_event_, aux_join_event_;

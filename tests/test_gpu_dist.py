@@ -35,7 +35,8 @@ def _model_bytes(rs, dims):
 
 
 @pytest.mark.parametrize("mom,avg", [(0.0, True), (0.5, True), (0.0, False)])
-def test_data_parallel_path_equals_stacked_bunch(hip, nn, tmp_path, mom, avg):
+@pytest.mark.parametrize("exchange", ["sum", "gather"])
+def test_data_parallel_path_equals_stacked_bunch(hip, nn, tmp_path, monkeypatch, mom, avg, exchange):
     rs = np.random.RandomState(11)
     dims = [40, 96, 64, 33]
     data, _ = _model_bytes(rs, dims)
@@ -49,6 +50,8 @@ def test_data_parallel_path_equals_stacked_bunch(hip, nn, tmp_path, mom, avg):
     try:
         dp = nn.Trainer(str(model))
         dp.set_train_opts(lr, mom, 0.0, 0.0, 0.0, avg, True)
+        # both exchanges: summed gradients (all-reduce) and gathered rows (all-gather + the fused update)
+        monkeypatch.setenv("KALDI_AMD_DP_EXCHANGE", exchange)
         dp.set_data_parallel(R)
         for s in range(steps):
             x = hip.DevMatrix.from_numpy(X[s])

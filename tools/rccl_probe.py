@@ -8,6 +8,7 @@ import sys
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ["KALDI_HIP_COMM_FORCE_RCCL"] = "1"   # one rank, but through ncclAllReduce / ncclAllGather all the same
 with_torch = len(sys.argv) > 1 and sys.argv[1] == "torch"
 if with_torch:
     import torch
@@ -29,6 +30,9 @@ x = np.arange(1 << 20, dtype=np.float32)
 d = h.DevMatrix.from_numpy(x, False)
 h.call("hipF_allreduce_sum", None, d.ptr, x.size)
 assert (d.numpy()[0] == x).all()
+g = h.DevMatrix(1, x.size, np.float32, pitched=False)
+h.call("hipF_allgather", None, d.ptr, g.ptr, x.size)
+assert (g.numpy()[0] == x).all()
 v = h.DevMatrix.from_numpy(np.array([7], np.int64), False)
 h.call("hipK_allreduce_i64", None, v.ptr, 1, 1)
 assert int(v.numpy()[0, 0]) == 7
