@@ -206,10 +206,17 @@ void Nnet::Backpropagate(const CuMatrix<BaseFloat> &in_err, CuMatrix<BaseFloat> 
         dp_in_all_[i].Resize(rows * dp_ranks_, input.NumCols());
         dp_err_all_[i].Resize(rows * dp_ranks_, err.NumCols());
       }
-      KALDI_ASSERT(dp_in_all_[i].Stride() == input.Stride() && dp_err_all_[i].Stride() == err.Stride());
+      KALDI_ASSERT(dp_err_all_[i].Stride() == err.Stride());
       CU_SAFE_CALL(hipK_stream_wait_event(dev.AuxStream(), layer_events_[i]));
-      CU_SAFE_CALL(hipF_allgather(dev.AuxStream(), input.Data(), dp_in_all_[i].Data(),
-                                  static_cast<size_t>(rows) * input.Stride()));
+      const BaseFloat *in_rows = input.Data();
+      if (dp_in_all_[i].Stride() != input.Stride()) {
+        // a caller's bunch with another row pitch (only the first layer's input can be one): repack first
+        CuStreamScope scope(dev.AuxStream());
+        dp_in_repack_.CopyFromMat(input);
+        in_rows = dp_in_repack_.Data();
+      }
+      CU_SAFE_CALL(hipF_allgather(dev.AuxStream(), in_rows, dp_in_all_[i].Data(),
+                                  static_cast<size_t>(rows) * dp_in_all_[i].Stride()));
       CU_SAFE_CALL(hipF_allgather(dev.AuxStream(), err.Data(), dp_err_all_[i].Data(),
                                   static_cast<size_t>(rows) * err.Stride()));
       dev.Order(dev.AuxStream(), dev.SideStream(), &grad_events_[i]);

@@ -102,6 +102,7 @@ class Nnet {
   std::vector<khEvent_t> read_events_;   // data-parallel: "back-propagation of layer i has read its weights"
   bool dp_gather_ = false;  // data-parallel by gathering every rank's (input, error) rows instead of summing gradients
   std::vector<CuMatrix<BaseFloat> > dp_in_all_, dp_err_all_;  // the gathered rows, per layer
+  CuMatrix<BaseFloat> dp_in_repack_;
   std::vector<BaseFloat *> dp_layer_grad_;  // data-parallel: one gradient buffer per layer
   std::vector<size_t> dp_layer_grad_size_;
   khEvent_t join_event_, aux_join_event_;
