@@ -37,7 +37,11 @@ int stream_ticket(hipStream_t st, unsigned **ticket) {
   if (rc != KH_OK) return rc;
   if (!w->ticket) {
     KH_HIP(hipMalloc((void **)&w->ticket, 256));
-    KH_HIP(hipMemset(w->ticket, 0, 256));
+    // Zeroed ON the stream whose kernels use it: hipMemset works on the null stream, with which a
+    // non-blocking stream has no ordering, and is not guaranteed to have finished when it returns
+    // (the first kernels then saw the allocation's old contents, nobody was "last", and the sums of
+    // those bunches were dropped).
+    KH_HIP(hipMemsetAsync(w->ticket, 0, 256, st));
   }
   *ticket = w->ticket;
   return KH_OK;

@@ -317,6 +317,36 @@ def test_recipe_scheduler_contract(hip, nn, tmp_path):
     assert accepted >= 2 and acc > first + 20.0, (first, acc, accepted)
 
 
+def test_tool_report_counts_every_frame(hip, nn, tmp_path):
+    """Every frame the tool processes must be in its report, from the first bunch of a fresh process on
+    (the loss kernel's "last workgroup adds up" counter was once zeroed off-stream and the sums of the first
+    bunches could be dropped).  Six fresh processes, fused and two-call loss, exact frame and correct counts."""
+    rs = np.random.RandomState(5)
+    dims = [24, 48, 10]
+    utts, alis = [], []
+    for i in range(10):
+        x = rs.randn(int(rs.randint(40, 120)), dims[0]).astype(f32)
+        utts.append(("u%03d" % i, x))
+        alis.append(("u%03d" % i, rs.randint(0, dims[-1], x.shape[0]).astype(np.int32)))
+    (tmp_path / "cv.ark").write_bytes(O.write_matrix_ark(utts))
+    (tmp_path / "cv.ali").write_bytes(O.write_int32_vector_ark(alis, binary=False))
+    layers = [O.BiasedLinearity((0.1 * rs.randn(dims[1], dims[0])).astype(f32), np.zeros(dims[1], f32)), O.Sigmoid(dims[1]),
+              O.BiasedLinearity((0.1 * rs.randn(dims[2], dims[1])).astype(f32), np.zeros(dims[2], f32)), O.Softmax(dims[2])]
+    (tmp_path / "0.nnet").write_bytes(O.write_nnet(layers, True))
+    X = np.concatenate([x for _, x in utts])
+    T = np.concatenate([a for _, a in alis])
+    n = X.shape[0] // 64 * 64                                     # the partial last bunch is dropped
+    correct = int((O.Nnet(layers).propagate(X[:n]).argmax(1) == T[:n]).sum())
+    for k in range(6):
+        extra = ["--fused=false"] if k % 2 else []
+        _, err = run_tool(nn, "nnet-train-xent-hardlab-frmshuff",
+                          ["--cross-validate=true", "--bunchsize=64", "--cachesize=1024"] + extra +
+                          ["ark:" + str(tmp_path / "cv.ark"), "ark:" + str(tmp_path / "cv.ali"), str(tmp_path / "0.nnet")])
+        assert int(re.search(r"frames:(\d+)", err).group(1)) == n, err[-600:]
+        acc = float(re.search(r"FRAME_ACCURACY >> (\S+)% <<", err).group(1))
+        assert abs(acc - 100.0 * correct / n) < 1e-3, (acc, correct, n)
+
+
 def test_train_tool_text_model_and_usage(hip, nn, tmp_path):
     g = load("train_e2e_small.npz")
     (tmp_path / "m.nnet").write_bytes(g["model"].tobytes())
