@@ -237,9 +237,9 @@ int hipK_gemm_timing_read(double *total_ms, double *busy_ms, long long *launches
  * the environment variable KALDI_HIP_GEMM_FORCE="bm,bn,splitk". */
 int hipK_gemm_force_plan(int bm, int bn, int splitk);
 
-/* Bytes of scratch hipF_gemm_ex / the fused entry points want for a given problem; the library
- * keeps one such workspace per process and grows it on demand (blocking), so callers only need
- * this to pre-size it before capturing a graph. */
+/* Pre-sizes the scratch workspace of the library's default stream (split-K slabs of hipF_gemm and of the
+ * fused entry points).  The library grows the workspace on demand (blocking: device synchronise + free +
+ * allocate), so callers only need this to keep that out of a timed or captured region. */
 int hipK_reserve_workspace(size_t bytes);
 
 /* ------------------------------------------------------------------------------------------
@@ -309,6 +309,16 @@ int hipF_affine_apply(khStream_t s, int32_t O, int32_t I, const float *grad, int
  * counters / loss live on the device and are read back by the caller when it reports. */
 int hipF_xent_eval(khStream_t s, const float *post, const int32_t *tgt, float *diff, float *log_post,
                    int32_t *max_id, long long *counters, double *loss, MatrixDim d);
+
+/* hipF_xent_eval for callers that cannot allocate (code under HIP graph capture, tight serving loops,
+ * harnesses that forbid hipMalloc).  No counterpart in the reference.  Same kernels and results as
+ * hipF_xent_eval; the arrival counter and the per-row scratch (used when log_post / max_id are NULL) live
+ * in a __device__ array of the library (256 B + 8 B x 65536 rows per GPU, held until the process ends)
+ * instead of allocated workspace.  Calls no hipMalloc / hipFree and does not initialise the library:
+ * returns KH_ERR_NOT_INITIALISED unless hipK_init has run, KH_ERR_TOO_LARGE for d.rows > 65536.
+ * Every call on a GPU shares that GPU's array: calls that overlap on one GPU (two streams) race. */
+int hipF_xent_eval_static(khStream_t s, const float *post, const int32_t *tgt, float *diff, float *log_post,
+                          int32_t *max_id, long long *counters, double *loss, MatrixDim d);
 
 /* The output layer of a training step in one call: hipF_affine_forward with KH_ACT_SOFTMAX followed by
  * hipF_xent_eval (nnet-biasedlinearity.h:58-63 + nnet-activation.h:233-236 + nnet-loss.cc:59-94), with the

@@ -39,6 +39,8 @@ inline hipStream_t pick(khStream_t s) { return s ? (hipStream_t)s : ctx().stream
 
 // The workspace of stream `st`, grown to at least `bytes` (blocking when it has to reallocate).
 int ensure_workspace(hipStream_t st, size_t bytes, void **ptr);
+// Looks up, for `device` (current), the device address of the static scratch of hipF_xent_eval_static.
+int static_scratch_setup(int device);
 // The arrival counter of stream `st` (device memory, zero whenever no kernel that uses it is queued).
 int stream_ticket(hipStream_t st, unsigned **ticket);
 

@@ -3,6 +3,33 @@
 // 64-lane wavefront reductions (DPP/shuffle), LDS only to combine the waves of a block.
 #include "common.h"
 
+// Scratch of hipF_xent_eval_static, the entry point that allocates nothing: the arrival counter of the
+// "last workgroup sums up" step (first 256 bytes) followed by the per-row results nobody asked for
+// (log-posterior and arg-max of kStaticXentRows rows).  Every GPU the library runs on holds its own
+// copy until the process ends; host code never passes the array's name to a kernel, only the
+// device address hipGetSymbolAddress returned for the current device.
+constexpr int kStaticXentRows = 65536;
+constexpr size_t kStaticTicketBytes = 256;
+static __device__ __align__(256) unsigned char scratch[kStaticTicketBytes + (size_t)kStaticXentRows * 8];
+
+namespace {
+constexpr int kMaxDevices = 64;
+unsigned char *g_scratch_ptr[kMaxDevices] = {nullptr};  // device address of `scratch`, per device ordinal
+}
+
+namespace kh {
+// Called by hipK_init with `device` current: looks the array's address up once per device.
+int static_scratch_setup(int device) {
+  if (device < 0 || device >= kMaxDevices) return KH_ERR_INVALID_ARG;
+  if (g_scratch_ptr[device]) return KH_OK;
+  unsigned char *ptr = nullptr;
+  KH_HIP(hipGetSymbolAddress((void **)&ptr, HIP_SYMBOL(scratch)));
+  if (!ptr) return KH_ERR_NOT_INITIALISED;
+  g_scratch_ptr[device] = ptr;
+  return KH_OK;
+}
+}  // namespace kh
+
 namespace {
 
 // ---- vec[c] = alpha * sum_r mat[r,c] + beta * vec[c] ---------------------------------------
@@ -666,6 +693,27 @@ KH_EXPORT int hipF_diff_xent(khStream_t s, const int32_t *vec_tgt, float *mat_ne
   return kh::launch_status();
 }
 
+namespace {
+// pass 1 + "last workgroup sums up" of Xent::EvalVec; lp / mi / ticket are valid device addresses
+int xent_eval_launch(hipStream_t st, const float *post, const int32_t *tgt, float *diff, float *lp, int32_t *mi,
+                     unsigned *ticket, long long *counters, double *loss, MatrixDim d) {
+  XentTail tail;
+  tail.counters = counters;
+  tail.loss = loss;
+  tail.ticket = ticket;
+  const bool vec = (post != diff) && (d.stride % 4 == 0) && kh::aligned16(post) && kh::aligned16(diff);
+  if (vec && d.cols <= 4096)
+    hipLaunchKernelGGL(xent_rows_vec_kernel<4>, dim3(d.rows), dim3(256), 0, st, post, tgt, diff, lp, mi, d, tail);
+  else if (vec && d.cols <= 10240)
+    hipLaunchKernelGGL(xent_rows_vec_kernel<10>, dim3(d.rows), dim3(256), 0, st, post, tgt, diff, lp, mi, d, tail);
+  else if (vec && d.cols <= 16384)
+    hipLaunchKernelGGL(xent_rows_vec_kernel<16>, dim3(d.rows), dim3(256), 0, st, post, tgt, diff, lp, mi, d, tail);
+  else
+    hipLaunchKernelGGL(xent_rows_kernel, dim3(d.rows), dim3(256), 0, st, post, tgt, diff, lp, mi, d, tail);
+  return kh::launch_status();
+}
+}  // namespace
+
 KH_EXPORT int hipF_xent_eval(khStream_t s, const float *post, const int32_t *tgt, float *diff, float *log_post,
                              int32_t *max_id, long long *counters, double *loss, MatrixDim d) {
   KH_CHECK_INIT();
@@ -683,23 +731,37 @@ KH_EXPORT int hipF_xent_eval(khStream_t s, const float *post, const int32_t *tgt
     if (!mi) mi = (int32_t *)((char *)ws + (size_t)d.rows * 4);
   }
   hipStream_t st = kh::pick(s);
-  XentTail tail;
-  tail.counters = counters;
-  tail.loss = loss;
+  unsigned *ticket;
   {
-    int rc = kh::stream_ticket(st, &tail.ticket);
+    int rc = kh::stream_ticket(st, &ticket);
     if (rc != KH_OK) return rc;
   }
-  const bool vec = (post != diff) && (d.stride % 4 == 0) && kh::aligned16(post) && kh::aligned16(diff);
-  if (vec && d.cols <= 4096)
-    hipLaunchKernelGGL(xent_rows_vec_kernel<4>, dim3(d.rows), dim3(256), 0, st, post, tgt, diff, lp, mi, d, tail);
-  else if (vec && d.cols <= 10240)
-    hipLaunchKernelGGL(xent_rows_vec_kernel<10>, dim3(d.rows), dim3(256), 0, st, post, tgt, diff, lp, mi, d, tail);
-  else if (vec && d.cols <= 16384)
-    hipLaunchKernelGGL(xent_rows_vec_kernel<16>, dim3(d.rows), dim3(256), 0, st, post, tgt, diff, lp, mi, d, tail);
-  else
-    hipLaunchKernelGGL(xent_rows_kernel, dim3(d.rows), dim3(256), 0, st, post, tgt, diff, lp, mi, d, tail);
-  return kh::launch_status();
+  return xent_eval_launch(st, post, tgt, diff, lp, mi, ticket, counters, loss, d);
+}
+
+// hipF_xent_eval for callers that cannot allocate: same kernels, the arrival counter and the per-row
+// scratch live in the file-scope `scratch` array.  No hipMalloc / hipFree, no implicit hipK_init.
+KH_EXPORT int hipF_xent_eval_static(khStream_t s, const float *post, const int32_t *tgt, float *diff,
+                                    float *log_post, int32_t *max_id, long long *counters, double *loss,
+                                    MatrixDim d) {
+  if (!kh::ctx().initialised) return KH_ERR_NOT_INITIALISED;  // (hipK_init allocates; the caller runs it beforehand)
+  KH_REQUIRE(kh::dim_ok(d));
+  if (d.rows == 0) return KH_OK;
+  KH_REQUIRE(post && tgt && diff && counters && loss && d.cols > 0);
+  if (d.rows > kStaticXentRows) {
+    snprintf(kh::ctx().last_msg, sizeof(kh::ctx().last_msg),
+             "hipF_xent_eval_static: %d rows, the static scratch holds at most %d", d.rows, kStaticXentRows);
+    return KH_ERR_TOO_LARGE;
+  }
+  const int dev = kh::ctx().device;
+  unsigned char *ptr = (dev >= 0 && dev < kMaxDevices) ? g_scratch_ptr[dev] : nullptr;
+  if (!ptr) return KH_ERR_NOT_INITIALISED;
+  hipStream_t st = kh::pick(s);
+  // the counter must start at zero whatever an earlier (possibly aborted) call left behind
+  KH_HIP(hipMemsetAsync(ptr, 0, kStaticTicketBytes, st));
+  float *lp = log_post ? log_post : (float *)(ptr + kStaticTicketBytes);
+  int32_t *mi = max_id ? max_id : (int32_t *)(ptr + kStaticTicketBytes + (size_t)kStaticXentRows * 4);
+  return xent_eval_launch(st, post, tgt, diff, lp, mi, (unsigned *)ptr, counters, loss, d);
 }
 
 KH_EXPORT int hipF_mse_eval(khStream_t s, const float *a, const float *b, float *diff, float *row_sq, double *loss,

@@ -132,6 +132,10 @@ KH_EXPORT int hipK_init(int device_id) {
     if (e && atoi(e) == 0) KH_HIP(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
     else KH_HIP(hipStreamCreateWithPriority(&c.stream, hipStreamNonBlocking, hi));
   }
+  {
+    int st = kh::static_scratch_setup(chosen);
+    if (st != KH_OK) return st;
+  }
   c.device = chosen;
   c.num_cu = prop.multiProcessorCount;
   c.initialised = true;
