@@ -231,6 +231,10 @@ int hipF_gemm(khStream_t s, int transA, int transB, int32_t M, int32_t N, int32_
  * Off by default. */
 int hipK_gemm_timing(int enable);
 int hipK_gemm_timing_read(double *total_ms, double *busy_ms, long long *launches, double *flops);
+/* The launches recorded since the last hipK_gemm_timing_read, in launch order, without clearing them: start
+ * (ms after the first launch's start), duration (ms) and algorithmic GFLOP of each; at most `cap` entries,
+ * *count receives how many were written.  Blocks until they have completed. */
+int hipK_gemm_timing_spans(double *start_ms, double *dur_ms, double *gflop, int cap, int *count);
 
 /* Tuning aid: pin the tile (bm x bn) and the split-K factor of every following GEMM instead of
  * letting the library choose; zeros restore the automatic choice.  Also settable at start-up with
@@ -273,6 +277,14 @@ int hipF_affine_backward(khStream_t s, int32_t N, int32_t O, int32_t I, const fl
 int hipF_affine_update(khStream_t s, int32_t N, int32_t O, int32_t I, const float *e, int32_t lde,
                        const float *in, int32_t ldin, float gscale, float momentum, float lr, float l2,
                        float *W, int32_t ldw, float *corr, int32_t ldcorr, float *bias, float *bcorr);
+
+/* hipF_affine_update with the new weights written to W_out (W_in itself, or a second O x I buffer as in
+ * hipF_affine_update_weights): weight pass and bias pass in ONE launch -- the bias sums are taken by a few
+ * extra workgroups at the end of the gradient GEMM's grid.  Same bits as the two halves below. */
+int hipF_affine_update_fused(khStream_t s, int32_t N, int32_t O, int32_t I, const float *e, int32_t lde,
+                             const float *in, int32_t ldin, float gscale, float momentum, float lr, float l2,
+                             const float *W_in, int32_t ldw_in, float *W_out, int32_t ldw_out, float *corr,
+                             int32_t ldcorr, float *bias, float *bcorr);
 
 /* The two halves of hipF_affine_update on their own, so that a caller can queue them on different
  * streams (the bias half reads only e; the weight half reads only e and in besides W):

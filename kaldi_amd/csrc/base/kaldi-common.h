@@ -1,5 +1,6 @@
 #ifndef KALDI_AMD_BASE_KALDI_COMMON_H_
 #define KALDI_AMD_BASE_KALDI_COMMON_H_
+#include <assert.h>
 #include <string.h>
 
 #include <iostream>

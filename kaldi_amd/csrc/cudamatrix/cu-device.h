@@ -88,9 +88,14 @@ class CuDevice {
     CU_SAFE_CALL(hipK_event_record(*ev, done));
     CU_SAFE_CALL(hipK_stream_wait_event(waiter, *ev));
   }
+  /// Blocks until everything queued on the library's streams has finished (the main stream and,
+  /// where they exist, the update streams: updates put off to the next forward pass may be the last
+  /// work of a training step).
   void Synchronize() {
     EnsureInit();
     CU_SAFE_CALL(hipK_stream_synchronize(main_stream_));
+    if (side_stream_ != NULL) CU_SAFE_CALL(hipK_stream_synchronize(side_stream_));
+    if (aux_stream_ != NULL) CU_SAFE_CALL(hipK_stream_synchronize(aux_stream_));
   }
   void EnsureInit() {
     if (!initialised_) SelectGpuId(requested_gpu_id_);

@@ -1,0 +1,838 @@
+// Device side of the fp32 MFMA GEMM: parameter block, kernels and their launchers.  Included by gemm.hip (host
+// logic: declarations only) and, with KHG_DEFINE_KERNELS, by the gemm_epi*.hip files, each of which compiles the
+// kernels of one epilogue (the build runs them in parallel; one file with every instantiation took minutes).
+#ifndef KALDI_AMD_CSRC_HIP_GEMM_KERNEL_H_
+#define KALDI_AMD_CSRC_HIP_GEMM_KERNEL_H_
+#include <type_traits>
+#include <utility>
+
+#include "common.h"
+
+#ifndef KH_SCHED
+#define KH_SCHED 3  // K-loop form: 0 group-by-group fragments, 2 whole-tile fragments, 3 whole-tile except in the update GEMMs
+#endif
+
+namespace khg {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+enum Epi {
+  EPI_AXPBY = 0,   // C = alpha*acc + beta*C
+  EPI_SLAB = 1,    // slab[ks] = acc                     (split-K partial)
+  EPI_BIAS_ACT = 2,// C = act(bias[col] + acc)
+  EPI_DSIG = 3,    // C = acc * y * (1 - y)
+  EPI_UPDATE = 4,  // corr = g*acc + mom*corr ; W = W - l2*W - lr*corr
+  EPI_RBM = 5      // dW = g*acc + dW - lrl2*W ; W += dW
+};
+
+struct GemmParams {
+  const float *A, *B;
+  int lda, ldb;
+  int M, N, K;
+  int splitk, k_per_split;
+  int a_bytes, b_bytes;  // operand footprints when both are below 2 GiB (buffer addressing), else 0
+  int tiles_m, tiles_n;
+  float alpha, beta;
+  float *C;
+  int ldc;
+  size_t slab_stride;
+  const float *bias;
+  const float *y;
+  int ldy;
+  const float *W;  // weights read by the update epilogues ...
+  int ldw;
+  float *Wout;     // ... and where the new ones go (may alias W)
+  int ldwout;
+  float lr, l2, mom;
+  int act;
+  int dyn_lds;     // extra LDS bytes to request at launch (caps how many workgroups share a compute unit)
+  // EPI_UPDATE only: the bias half of the update, done by `bias_tiles` extra workgroups at the end of the grid
+  // (bias_io -= lr * (alpha * colsum(A) + mom * bcorr); A is the error matrix, K x M as stored)
+  float *bias_io;
+  float *bcorr;
+  int bias_tiles;
+#ifdef KH_GEMM_STAMPS
+  unsigned long long *stamps;
+#endif
+};
+
+constexpr int kBK = 32;
+
+// launches the main kernel for tile configuration `cfg` (index into the planner's table) and operand layout
+template <int EPI>
+void launch_layout(hipStream_t st, const GemmParams &p, int cfg, bool vec, bool a_kmajor, bool b_kmajor);
+// sums split-K slabs and applies epilogue EPI
+template <int EPI>
+void launch_reduce(hipStream_t st, const GemmParams &p, const float *slabs, int ld_slab);
+
+#ifdef KHG_DEFINE_KERNELS
+
+#ifdef KH_GEMM_STAMPS
+// diagnostic build only: cycle stamps of wave 0 of every workgroup, 16 slots per workgroup
+#define KH_STAMP(i)                                                                     \
+  do {                                                                                  \
+    if (p.stamps && threadIdx.x == 0) p.stamps[(size_t)blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+#else
+#define KH_STAMP(i) do { } while (0)
+#endif
+
+// The epilogue's second operand of one output element, fetched before any store so that the
+// loads of all elements of a lane are in flight together: the bias of the column, or y.  Row and
+// column are clamped into the matrix (elements outside are computed but never stored).
+template <int EPI>
+__device__ __forceinline__ float epi_aux(const GemmParams &p, int row, int col) {
+  if (EPI == EPI_BIAS_ACT) return p.bias[min(col, p.N - 1)];
+  if (EPI == EPI_DSIG) return p.y[(size_t)min(row, p.M - 1) * p.ldy + min(col, p.N - 1)];
+  return 0.f;
+}
+
+// The arithmetic of the epilogue that needs no memory: done for every element of a lane before
+// the guarded stores, so the wait for the operand loads happens once, not in front of every store
+// (where it would also wait for the store before it).
+template <int EPI>
+__device__ __forceinline__ float epi_value(const GemmParams &p, float acc, float aux) {
+  if (EPI == EPI_BIAS_ACT) {
+    const float v = acc + aux;
+    return p.act == KH_ACT_SIGMOID ? kh::sigmoidf(v) : v;
+  }
+  if (EPI == EPI_DSIG) return aux * (1.0f - aux) * acc;
+  return acc;
+}
+
+template <int EPI>
+__device__ __forceinline__ void epi_store(const GemmParams &p, int row, int col, float val, int ks) {
+  if (EPI == EPI_SLAB) {
+    p.C[(size_t)ks * p.slab_stride + (size_t)row * p.ldc + col] = val;
+  } else if (EPI == EPI_AXPBY) {
+    float *c = p.C + (size_t)row * p.ldc + col;
+    *c = (p.beta == 0.f) ? p.alpha * val : p.alpha * val + p.beta * *c;
+  } else if (EPI == EPI_BIAS_ACT || EPI == EPI_DSIG) {
+    p.C[(size_t)row * p.ldc + col] = val;
+  } else if (EPI == EPI_UPDATE) {
+    float c = p.alpha * val;
+    if (p.mom != 0.f) c += p.mom * p.C[(size_t)row * p.ldc + col];
+    if (p.C) p.C[(size_t)row * p.ldc + col] = c;
+    float wv = p.W[(size_t)row * p.ldw + col];
+    if (p.l2 != 0.f) wv = -p.l2 * wv + wv;
+    p.Wout[(size_t)row * p.ldwout + col] = -p.lr * c + wv;
+  } else if (EPI == EPI_RBM) {
+    float *dw = p.C + (size_t)row * p.ldc + col;
+    const float wv = p.W[(size_t)row * p.ldw + col];
+    float d = p.alpha * val + *dw;
+    d = -p.l2 * wv + d;
+    *dw = d;
+    p.Wout[(size_t)row * p.ldwout + col] = d + wv;
+  }
+}
+
+// BM x BN output tile, 4 waves arranged WAVES_M x WAVES_N x WK.  A K-tile is BKT = BK*WK deep and
+// wave-slice wk of it (BK = 32 k) goes to the waves with that wk: with WK > 1 the waves of a
+// workgroup split K among themselves and add their accumulators through LDS before the epilogue.
+// That keeps 256 workgroups (one per CU) on a 256-row x 2048-column product with 32x64 tiles and
+// the whole K inside the workgroup, so the epilogue can finish the element (bias, sigmoid, ...)
+// instead of writing a partial slab for a second kernel.
+// A_KMAJOR: A(m,k) at A[m*lda+k] (k contiguous), otherwise A[k*lda+m].  Same for B with n.
+// VEC: every row base is 16-byte aligned and leading dimensions are multiples of 4 floats.
+// floats of LDS one workgroup of gemm_tile<...> needs (two buffers of an A image and a B image)
+template <int BM, int BN, int BK, int WK, bool A_KMAJOR, bool B_KMAJOR>
+constexpr int gemm_lds_floats() {
+  constexpr int BKT = BK * WK;
+  constexpr int PA = A_KMAJOR ? (BKT + 4) : BM, PB = B_KMAJOR ? (BKT + 4) : BN;
+  return 2 * ((A_KMAJOR ? BM * PA : BKT * PA) + (B_KMAJOR ? BN * PB : BKT * PB));
+}
+
+// One output tile by one workgroup: tile `bid` of the `nblk` this product is cut into (`bid` must be
+// congruent to blockIdx.x modulo 8 for the XCD-aware decode below to keep its meaning).
+template <int BM, int BN, int BK, int WK, bool A_KMAJOR, bool B_KMAJOR, int EPI, bool VEC>
+__device__ __forceinline__ void gemm_tile(const GemmParams &p, float *lds, const int bid, const int nblk) {
+  constexpr int NT = 256;
+  constexpr int WAVES_M = (WK == 1) ? 2 : 1, WAVES_N = (WK == 4) ? 1 : 2;
+  static_assert(WAVES_M * WAVES_N * WK == 4, "4 waves per workgroup");
+  constexpr int BKT = BK * WK;                          // K depth of one staged tile
+  constexpr int TM = BM / (WAVES_M * 32), TN = BN / (WAVES_N * 32);
+  static_assert(TM >= 1 && TN >= 1, "tile too small for this wave arrangement");
+  constexpr int PA = A_KMAJOR ? (BKT + 4) : BM;        // LDS pitch of the A image (floats)
+  constexpr int PB = B_KMAJOR ? (BKT + 4) : BN;
+  constexpr int A_ELEMS = A_KMAJOR ? BM * PA : BKT * PA;
+  constexpr int B_ELEMS = B_KMAJOR ? BN * PB : BKT * PB;
+  constexpr int A_UNITS = BM * BKT / 4 / NT;           // float4 loads per thread per K-tile
+  constexpr int B_UNITS = BN * BKT / 4 / NT;
+  static_assert(A_UNITS >= 1 && B_UNITS >= 1, "tile too small for 256 threads");
+  static_assert(2 * (A_ELEMS + B_ELEMS) == gemm_lds_floats<BM, BN, BK, WK, A_KMAJOR, B_KMAJOR>(), "LDS size helper out of step");
+
+  // ---- which tile: XCD-aware decode of the linear block id -----------------------------------
+  // Blocks b and b+8 run on the same XCD (same L2); give each XCD a contiguous run of tiles so
+  // that neighbours, which share the B (weight) panel, hit in that L2.
+  KH_STAMP(0);
+  // The products of the dependent chain (forward, back-propagation) outrank the weight updates that
+  // fill the compute units beside them: where waves of both share a SIMD, the chain's issue first.
+#ifndef KH_NO_CHAIN_PRIO
+  if (EPI != EPI_UPDATE && EPI != EPI_RBM) __builtin_amdgcn_s_setprio(3);
+#endif
+  int L = bid;
+  if ((nblk & 7) == 0) L = (L & 7) * (nblk >> 3) + (L >> 3);
+  const int mi = L % p.tiles_m;
+  L /= p.tiles_m;
+  const int ks = L % p.splitk;
+  const int ni = L / p.splitk;
+  const int m0 = mi * BM, n0 = ni * BN;
+  const int kbeg = ks * p.k_per_split;
+  const int kend = min(p.K, kbeg + p.k_per_split);
+  const int nkt = (kend - kbeg + BKT - 1) / BKT;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wid = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int wk = wid / (WAVES_M * WAVES_N);  // which K slice of every tile this wave multiplies
+  const int wm0 = ((wid / WAVES_N) % WAVES_M) * (TM * 32), wn0 = (wid % WAVES_N) * (TN * 32);
+
+  float4 ra[A_UNITS], rb[B_UNITS];
+
+  // Loads of one K-tile into registers, two forms.
+  // fast: VEC layout and every k of the tile inside [kbeg,kend).  Unconditional 16-byte loads from
+  //   per-thread base pointers -- rows / columns past the matrix edge are redirected to the last
+  //   valid one, their products only reach output elements that are never stored -- so all loads
+  //   of a tile are in flight together and no wait sits between them.
+  // slow: guarded element-wise loads with zero fill (the K-tail tile, unaligned operands).
+  // The fast loads are buffer loads: one resource descriptor per operand in SGPRs, a 32-bit byte
+  // offset per thread and unit, the K-tile advance as a scalar offset.  Measured beside MFMAs,
+  // global_load with 64-bit per-lane addresses roughly doubles the cost of a K-tile; the buffer
+  // form is nearly free (tools/mfma_probe2.hip), and out-of-range offsets return 0 instead of faulting.
+  typedef int v4i __attribute__((ext_vector_type(4)));
+  const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc((void *)p.A, 0, p.a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc((void *)p.B, 0, p.b_bytes, 0x00020000);
+  int oa[A_UNITS], ob[B_UNITS];  // byte offsets of this thread's units in K-tile 0
+  int a_step, b_step;            // byte advance per K-tile
+  {
+    const int a_xlast = ((p.M - 1) >> 2) << 2, b_xlast = ((p.N - 1) >> 2) << 2;
+#pragma unroll
+    for (int u = 0; u < A_UNITS; ++u) {
+      const int unit = tid + u * NT;
+      if (A_KMAJOR) {
+        const int row = unit / (BKT / 4), kq = unit % (BKT / 4);
+        oa[u] = (min(m0 + row, p.M - 1) * p.lda + (kbeg + kq * 4)) * 4;
+      } else {
+        const int krow = unit / (BM / 4), mq = unit % (BM / 4);
+        oa[u] = ((kbeg + krow) * p.lda + min(m0 + mq * 4, a_xlast)) * 4;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < B_UNITS; ++u) {
+      const int unit = tid + u * NT;
+      if (B_KMAJOR) {
+        const int row = unit / (BKT / 4), kq = unit % (BKT / 4);
+        ob[u] = (min(n0 + row, p.N - 1) * p.ldb + (kbeg + kq * 4)) * 4;
+      } else {
+        const int krow = unit / (BN / 4), nq = unit % (BN / 4);
+        ob[u] = ((kbeg + krow) * p.ldb + min(n0 + nq * 4, b_xlast)) * 4;
+      }
+    }
+    a_step = (A_KMAJOR ? BKT : BKT * p.lda) * 4;
+    b_step = (B_KMAJOR ? BKT : BKT * p.ldb) * 4;
+  }
+  auto buf_load = [&](const __amdgpu_buffer_rsrc_t &rs, int voff, int soff) {
+    const v4i r = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0);
+    return make_float4(__int_as_float(r.x), __int_as_float(r.y), __int_as_float(r.z), __int_as_float(r.w));
+  };
+  auto load_fast = [&](int kt) {
+#pragma unroll
+    for (int u = 0; u < A_UNITS; ++u) ra[u] = buf_load(rsrc_a, oa[u], kt * a_step);
+#pragma unroll
+    for (int u = 0; u < B_UNITS; ++u) rb[u] = buf_load(rsrc_b, ob[u], kt * b_step);
+  };
+  auto load_slow = [&](int kt) {
+    const int k0 = kbeg + kt * BKT;
+#pragma unroll
+    for (int u = 0; u < A_UNITS; ++u) {
+      const int unit = tid + u * NT;
+      float v[4] = {0.f, 0.f, 0.f, 0.f};
+      if (A_KMAJOR) {
+        const int row = unit / (BKT / 4), kq = unit % (BKT / 4);
+        const int m = m0 + row, k = k0 + kq * 4;
+        if (m < p.M) {
+          const float *src = p.A + (size_t)m * p.lda + k;
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (k + e < kend) v[e] = src[e];
+        }
+      } else {
+        const int krow = unit / (BM / 4), mq = unit % (BM / 4);
+        const int k = k0 + krow, m = m0 + mq * 4;
+        if (k < kend) {
+          const float *src = p.A + (size_t)k * p.lda + m;
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (m + e < p.M) v[e] = src[e];
+        }
+      }
+      ra[u] = make_float4(v[0], v[1], v[2], v[3]);
+    }
+#pragma unroll
+    for (int u = 0; u < B_UNITS; ++u) {
+      const int unit = tid + u * NT;
+      float v[4] = {0.f, 0.f, 0.f, 0.f};
+      if (B_KMAJOR) {
+        const int row = unit / (BKT / 4), kq = unit % (BKT / 4);
+        const int n = n0 + row, k = k0 + kq * 4;
+        if (n < p.N) {
+          const float *src = p.B + (size_t)n * p.ldb + k;
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (k + e < kend) v[e] = src[e];
+        }
+      } else {
+        const int krow = unit / (BN / 4), nq = unit % (BN / 4);
+        const int k = k0 + krow, n = n0 + nq * 4;
+        if (k < kend) {
+          const float *src = p.B + (size_t)k * p.ldb + n;
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (n + e < p.N) v[e] = src[e];
+        }
+      }
+      rb[u] = make_float4(v[0], v[1], v[2], v[3]);
+    }
+  };
+  auto store_tiles = [&](int buf) {
+    float *As = lds + buf * (A_ELEMS + B_ELEMS);
+    float *Bs = As + A_ELEMS;
+#pragma unroll
+    for (int u = 0; u < A_UNITS; ++u) {
+      const int unit = tid + u * NT;
+      if (A_KMAJOR) {
+        const int row = unit / (BKT / 4), kq = unit % (BKT / 4);
+        *reinterpret_cast<float4 *>(As + row * PA + kq * 4) = ra[u];
+      } else {
+        const int krow = unit / (BM / 4), mq = unit % (BM / 4);
+        *reinterpret_cast<float4 *>(As + krow * PA + mq * 4) = ra[u];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < B_UNITS; ++u) {
+      const int unit = tid + u * NT;
+      if (B_KMAJOR) {
+        const int row = unit / (BKT / 4), kq = unit % (BKT / 4);
+        *reinterpret_cast<float4 *>(Bs + row * PB + kq * 4) = rb[u];
+      } else {
+        const int krow = unit / (BN / 4), nq = unit % (BN / 4);
+        *reinterpret_cast<float4 *>(Bs + krow * PB + nq * 4) = rb[u];
+      }
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // ---- operand fragments ------------------------------------------------------------------------
+  // One group = 8 k = 4 MFMA steps per accumulator.  A fragment is fetched by RN single LDS read
+  // instructions (one 16-byte read per 32-row block of a K-contiguous operand, four 4-byte reads
+  // otherwise), numbered so that the pipelined loop can place them one by one.
+  struct Frag {
+    float a[TM][4], b[TN][4];
+  };
+  constexpr int RN_A = A_KMAJOR ? TM : 4 * TM, RN_B = B_KMAJOR ? TN : 4 * TN, RN = RN_A + RN_B;
+  const int a_lds = A_KMAJOR ? (wm0 + li) * PA + wk * BK + lh * 4 : (wk * BK + lh * 4) * PA + wm0 + li;
+  const int b_lds = A_ELEMS + (B_KMAJOR ? (wn0 + li) * PB + wk * BK + lh * 4 : (wk * BK + lh * 4) * PB + wn0 + li);
+  auto read_op = [&](Frag &f, const float *base, int g, int r) {
+    if (r < RN_A) {
+      if (A_KMAJOR) {
+        const float4 t = *reinterpret_cast<const float4 *>(base + a_lds + r * 32 * PA + g * 8);
+        f.a[r][0] = t.x; f.a[r][1] = t.y; f.a[r][2] = t.z; f.a[r][3] = t.w;
+      } else {
+        f.a[r >> 2][r & 3] = base[a_lds + (g * 8 + (r & 3)) * PA + (r >> 2) * 32];
+      }
+    } else {
+      r -= RN_A;
+      if (B_KMAJOR) {
+        const float4 t = *reinterpret_cast<const float4 *>(base + b_lds + r * 32 * PB + g * 8);
+        f.b[r][0] = t.x; f.b[r][1] = t.y; f.b[r][2] = t.z; f.b[r][3] = t.w;
+      } else {
+        f.b[r >> 2][r & 3] = base[b_lds + (g * 8 + (r & 3)) * PB + (r >> 2) * 32];
+      }
+    }
+  };
+  // one register-staged 16-byte unit of the next tile: registers -> LDS, global -> registers
+  constexpr int NC = A_UNITS + B_UNITS;
+  auto write_op = [&](float *base, int c) {
+    const float4 &va = ra[c < A_UNITS ? c : 0];
+    const float4 &vb = rb[c < A_UNITS ? 0 : c - A_UNITS];
+    if (c < A_UNITS) {
+      const int unit = tid + c * NT;
+      const int off = A_KMAJOR ? (unit / (BKT / 4)) * PA + (unit % (BKT / 4)) * 4 : (unit / (BM / 4)) * PA + (unit % (BM / 4)) * 4;
+      *reinterpret_cast<float4 *>(base + off) = va;
+    } else {
+      const int unit = tid + (c - A_UNITS) * NT;
+      const int off = B_KMAJOR ? (unit / (BKT / 4)) * PB + (unit % (BKT / 4)) * 4 : (unit / (BN / 4)) * PB + (unit % (BN / 4)) * 4;
+      *reinterpret_cast<float4 *>(base + A_ELEMS + off) = vb;
+    }
+  };
+  auto load_op = [&](int c, int kt) {
+    const float4 v = (c < A_UNITS) ? buf_load(rsrc_a, oa[c < A_UNITS ? c : 0], kt * a_step)
+                                   : buf_load(rsrc_b, ob[c < A_UNITS ? 0 : c - A_UNITS], kt * b_step);
+    if (c < A_UNITS) ra[c] = v; else rb[c - A_UNITS] = v;
+  };
+  // MFMAs of one K-tile out of LDS buffer `buf`, unpipelined (K tail, unaligned operands)
+  auto compute = [&](int buf) {
+    const float *base = lds + buf * (A_ELEMS + B_ELEMS);
+#pragma unroll
+    for (int g = 0; g < BK / 8; ++g) {
+      Frag f;
+#pragma unroll
+      for (int r = 0; r < RN; ++r) read_op(f, base, g, r);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int q = 0; q < TN; ++q)
+            acc[i][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[i][j], f.b[q][j], acc[i][q], 0, 0, 0);
+    }
+  };
+  // Workgroup barrier that drains this wave's LDS traffic only: global loads issued for a later
+  // K-tile stay in flight across it (__syncthreads would wait for them too).
+  auto lds_barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+
+  // Epilogue operand fetched under the main loop (the weight tile of the update GEMM): one
+  // accumulator's worth per K-tile, so that the read-modify-write at the end starts with the old
+  // weights already in registers instead of every workgroup hitting HBM at the same moment.
+  constexpr bool PREFETCH = (EPI == EPI_UPDATE);
+  static_assert(!(PREFETCH && WK > 1), "the update epilogue is not built for K split over waves");
+  constexpr int NPRE = PREFETCH ? TM * TN : 1;
+  float pre[NPRE][16];
+  const bool full_tile = (m0 + BM <= p.M) && (n0 + BN <= p.N);
+  int npre = 0;  // accumulators whose operand is in `pre`
+  auto prefetch_acc = [&](int a) {
+    const int i = a / TN, q = a % TN;
+    const float *src = p.W + (size_t)(m0 + wm0 + i * 32 + 4 * lh) * p.ldw + (n0 + wn0 + q * 32 + li);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) pre[a][r] = src[(size_t)((r & 3) + 8 * (r >> 2)) * p.ldw];
+  };
+
+  // K-tiles completely inside the split take the fast loads; at most one tail tile does not.
+  const int nfull = (VEC && p.a_bytes > 0) ? (kend - kbeg) / BKT : 0;
+  constexpr int G = BK / 8;           // k-groups per tile
+  // which K-loop: whole-tile operand fragments (more registers: 2 waves per SIMD at most) or
+  // group-by-group fragments (the update GEMMs, which run 4 workgroups per CU)
+  constexpr bool kWholeTile = (KH_SCHED == 2) || (KH_SCHED == 3 && EPI != EPI_UPDATE && EPI != EPI_RBM);
+  constexpr int MG = 4 * TM * TN;     // MFMAs per group
+  static_assert(G >= 4 && G % 2 == 0, "BK must be a multiple of 16, at least 32");
+  int kt = 0;
+  if (nfull == 0) {
+    // unaligned operands or a K range shorter than one tile: plain double-buffered loop
+    if (nkt > 0) {
+      load_slow(0);
+      store_tiles(0);
+    }
+    __syncthreads();
+    for (; kt < nkt; ++kt) {
+      const bool more = (kt + 1 < nkt);
+      if (more) load_slow(kt + 1);
+      compute(kt & 1);
+      if (more) store_tiles((kt + 1) & 1);
+      __syncthreads();
+    }
+  } else {
+    // Software pipeline inside the wave (one wave per SIMD has nobody else to hide its latencies):
+    // the memory instructions of the NEXT tiles are placed one by one behind the MFMAs of this
+    // one and pinned there with scheduling barriers, so that they issue in the MFMAs' shadow.
+    // Measured beside a chain of MFMAs (tools/mfma_probe2.hip, mfma_probe4.hip): a gap between two
+    // MFMAs that holds other instructions costs ~8 cycles whatever is in it (as long as it issues
+    // within the MFMA's 64 cycles), an empty gap nothing.  Two forms follow.
+    if constexpr (kWholeTile) {
+    // Whole-tile operand fragments.  The operands of ALL k-groups of a tile are held in registers,
+    // double-buffered across tiles, so a tile is NM = G*MG MFMAs in a row with only
+    //   * one gap per copy unit (LDS store of the next tile + buffer load for the tile after), and
+    //   * behind MFMA SB: the wait for this wave's LDS stores, the barrier, and the LDS reads of
+    //     the whole next tile (8 read instructions per gap, consecutive gaps).
+    // Measured (tools/mfma_probe4.hip): 1068 cycles per 64x64x32 tile against 1024 of MFMA, where
+    // reading group by group takes ~1250.
+    load_fast(0);
+    KH_STAMP(1);
+    store_tiles(0);
+    KH_STAMP(2);
+    __syncthreads();
+    KH_STAMP(3);
+    if (nfull > 1) load_fast(1);
+    Frag fr[2][G];
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+      for (int r = 0; r < RN; ++r) read_op(fr[0][g], lds, g, r);
+    constexpr int NM = G * MG;            // MFMAs per tile
+    constexpr int NREAD = G * RN;         // LDS read instructions per tile
+    constexpr int RGAPS = (NREAD + 7) / 8;
+    constexpr int SB = NM - 2 - RGAPS;    // MFMA slot behind which the barrier and the first reads go
+    static_assert(SB >= 1 + NC, "tile too small for this schedule");
+    auto tile_body = [&](auto last_tag, auto par_tag) {
+      constexpr bool LAST = decltype(last_tag)::value;
+      constexpr int PAR = decltype(par_tag)::value;  // = kt & 1: LDS buffer and fragment set of this tile
+      float *nxt = lds + (PAR ^ 1) * (A_ELEMS + B_ELEMS);
+      const int kt_load = min(kt + 2, nfull - 1);  // past the end: a harmless repeat of the last tile
+#pragma unroll
+      for (int m = 0; m < NM; ++m) {
+        const int g = m / MG, t = m % MG;
+        const int j = t / (TM * TN), i = (t % (TM * TN)) / TN, q = t % TN;
+        acc[i][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(fr[PAR][g].a[i][j], fr[PAR][g].b[q][j], acc[i][q], 0, 0, 0);
+        if (!LAST) {
+#pragma unroll
+          for (int c = 0; c < NC; ++c)
+            if (1 + (c * (SB - 1)) / NC == m) {
+#if defined(KH_GEMM_STAMPS) && defined(KH_ABL)
+              // timing ablations of the diagnostic build (wrong results on purpose): 1 no LDS stores, 2 no loads, 3 neither
+              if (KH_ABL != 1 && KH_ABL != 3) write_op(nxt, c);
+              if (KH_ABL != 2 && KH_ABL != 3) load_op(c, kt_load);
+#else
+              write_op(nxt, c);
+              load_op(c, kt_load);
+#endif
+            }
+          if (m >= SB && m < SB + RGAPS) {
+#if defined(KH_GEMM_STAMPS) && defined(KH_ABL) && KH_ABL >= 4
+            if (m == SB && KH_ABL != 4) lds_barrier();  // 4: no barrier
+#else
+            if (m == SB) lds_barrier();
+#endif
+#pragma unroll
+            for (int x = (m - SB) * 8; x < (m - SB + 1) * 8 && x < NREAD; ++x)
+              read_op(fr[PAR ^ 1][x / RN], nxt, x / RN, x % RN);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+    auto steady = [&](auto par_tag) {
+      if (PREFETCH && full_tile) {
+#pragma unroll
+        for (int a = 0; a < NPRE; ++a)
+          if (kt == a) {
+            prefetch_acc(a);
+            npre = a + 1;
+          }
+      }
+      tile_body(std::false_type(), par_tag);
+    };
+    // two tiles per trip, no exit in the middle: the fragment sets and accumulators then keep
+    // their registers around the back edge (a mid-loop exit made the compiler copy all of them)
+    while (kt + 2 < nfull) {
+      steady(std::integral_constant<int, 0>());
+      ++kt;
+      steady(std::integral_constant<int, 1>());
+      ++kt;
+    }
+    const bool tail = nkt > nfull;  // the K tail, at most one partial tile
+    if (kt + 1 < nfull) {           // kt is even here
+      steady(std::integral_constant<int, 0>());
+      ++kt;
+      KH_STAMP(4);
+      if (tail) load_slow(nfull);
+      tile_body(std::true_type(), std::integral_constant<int, 1>());
+    } else {
+      KH_STAMP(4);
+      if (tail) load_slow(nfull);
+      tile_body(std::true_type(), std::integral_constant<int, 0>());
+    }
+    if (tail) {
+      store_tiles(nfull & 1);
+      __syncthreads();
+      compute(nfull & 1);
+    }
+    } else {
+    load_fast(0);
+    KH_STAMP(1);
+    store_tiles(0);
+    KH_STAMP(2);
+    __syncthreads();
+    KH_STAMP(3);
+    if (nfull > 1) load_fast(1);
+    Frag fr[2];
+#pragma unroll
+    for (int r = 0; r < RN; ++r) read_op(fr[0], lds, 0, r);
+
+    // Group-by-group fragments (the update GEMMs): two fragment buffers; the LDS reads of group
+    // g+1 go behind the first MFMAs of group g, the copy units behind the MFMAs of the second half
+    // of groups 1..G-2 (an LDS store never sits in the queue in front of the next group's
+    // operand reads), the one barrier per tile behind the first MFMA of the last group.
+    auto tile_body = [&](auto last_tag) {
+      constexpr bool LAST = decltype(last_tag)::value;
+      float *cur = lds + (kt & 1) * (A_ELEMS + B_ELEMS);
+      float *nxt = lds + ((kt + 1) & 1) * (A_ELEMS + B_ELEMS);
+      const int kt_load = min(kt + 2, nfull - 1);  // past the end: a harmless repeat of the last tile
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+#pragma unroll
+        for (int t = 0; t < MG; ++t) {
+          const int j = t / (TM * TN), i = (t % (TM * TN)) / TN, q = t % TN;
+          acc[i][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(fr[g & 1].a[i][j], fr[g & 1].b[q][j], acc[i][q], 0, 0, 0);
+          // reads of group g+1 behind the first MFMAs of group g, copies in the second half of groups 1..G-2
+          constexpr int RPS = (RN + (MG / 2) - 1) / (MG / 2);
+          if (g + 1 < G) {
+#pragma unroll
+            for (int r = 0; r < RN; ++r)
+              if (r / RPS == t) read_op(fr[(g + 1) & 1], cur, g + 1, r);
+          } else if (!LAST) {
+            if (t == 0) lds_barrier();
+#pragma unroll
+            for (int r = 0; r < RN; ++r)
+              if (r / RPS == t) read_op(fr[0], nxt, 0, r);
+          }
+          if (!LAST && g >= 1 && g <= G - 2) {
+            constexpr int PER = (NC + (G - 2) - 1) / (G - 2);
+            constexpr int STEP = (MG / 2) / PER > 0 ? (MG / 2) / PER : 1;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+              const int tt = MG / 2 + (c % PER) * STEP;
+              if ((1 + c / PER) * MG + (tt < MG ? tt : MG - 1) == g * MG + t) {
+                write_op(nxt, c);
+                load_op(c, kt_load);
+              }
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    };
+    auto steady = [&]() {
+      if (PREFETCH && full_tile) {
+#pragma unroll
+        for (int a = 0; a < NPRE; ++a)
+          if (kt == a) {
+            prefetch_acc(a);
+            npre = a + 1;
+          }
+      }
+      tile_body(std::false_type());
+    };
+    for (; kt + 1 < nfull; ++kt) steady();
+    KH_STAMP(4);
+    const bool tail = nkt > nfull;  // the K tail, at most one partial tile
+    if (tail) load_slow(nfull);
+    tile_body(std::true_type());
+    if (tail) {
+      store_tiles(nfull & 1);
+      __syncthreads();
+      compute(nfull & 1);
+    }
+    }
+  }
+
+  KH_STAMP(5);
+  // ---- epilogue: accumulator register r of lane (li, lh) is C[(r&3) + 8*(r>>2) + 4*lh][li] ------
+  if constexpr (WK == 1) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int q = 0; q < TN; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          const int col = n0 + wn0 + q * 32 + li;
+          if (PREFETCH && i * TN + q < npre) {
+            // full tile, old weight already here (same arithmetic as epi_store<EPI_UPDATE>)
+            float c = p.alpha * acc[i][q][r];
+            if (p.mom != 0.f) c += p.mom * p.C[(size_t)row * p.ldc + col];
+            if (p.C) p.C[(size_t)row * p.ldc + col] = c;
+            float wv = pre[PREFETCH ? i * TN + q : 0][r];
+            if (p.l2 != 0.f) wv = -p.l2 * wv + wv;
+            p.Wout[(size_t)row * p.ldwout + col] = -p.lr * c + wv;
+          } else if (row < p.M && col < p.N) {
+            epi_store<EPI>(p, row, col, epi_value<EPI>(p, acc[i][q][r], epi_aux<EPI>(p, row, col)), ks);
+          }
+        }
+  } else {
+    // K split over the waves: wave wk finishes registers [wk*RS, (wk+1)*RS) of every accumulator.
+    // Every wave puts all its registers into LDS (the tile buffers are free now), sorted by owner;
+    // the owner adds the WK partial sums in the order of wk, so the result does not depend on
+    // timing.  Register numbers stay compile-time constants this way (only addresses depend on
+    // wk); selecting registers by wk made the compiler emit a 16-way select per element.
+    // Exchange image: [spatial wave][owner][source][accumulator][register][lane].
+    constexpr int RS = 16 / WK;
+    constexpr int NACC = TM * TN;
+    constexpr int XCH = WK * WK * NACC * RS * 64;  // floats per spatial wave position
+    static_assert(WAVES_M * WAVES_N * XCH <= 2 * (A_ELEMS + B_ELEMS), "exchange image larger than the tile buffers");
+    float *xch = lds + (wid % (WAVES_M * WAVES_N)) * XCH;
+    lds_barrier();  // every wave is done reading operand tiles
+#pragma unroll
+    for (int o = 0; o < WK; ++o)
+#pragma unroll
+      for (int a = 0; a < NACC; ++a)
+#pragma unroll
+        for (int rr = 0; rr < RS; ++rr)
+          xch[(((o * WK + wk) * NACC + a) * RS + rr) * 64 + lane] = acc[a / TN][a % TN][o * RS + rr];
+    float aux[NACC][RS];
+#pragma unroll
+    for (int a = 0; a < NACC; ++a)
+#pragma unroll
+      for (int rr = 0; rr < RS; ++rr) {
+        const int r = wk * RS + rr;
+        aux[a][rr] = epi_aux<EPI>(p, m0 + wm0 + (a / TN) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, n0 + wn0 + (a % TN) * 32 + li);
+      }
+    lds_barrier();  // (not __syncthreads: the loads just issued stay in flight across it)
+    float sum[NACC][RS];
+#pragma unroll
+    for (int a = 0; a < NACC; ++a)
+#pragma unroll
+      for (int rr = 0; rr < RS; ++rr)
+#pragma unroll
+        for (int src = 0; src < WK; ++src) {
+          const float part = xch[(((wk * WK + src) * NACC + a) * RS + rr) * 64 + lane];
+          sum[a][rr] = (src == 0) ? part : sum[a][rr] + part;
+        }
+#pragma unroll
+    for (int a = 0; a < NACC; ++a)
+#pragma unroll
+      for (int rr = 0; rr < RS; ++rr) sum[a][rr] = epi_value<EPI>(p, sum[a][rr], aux[a][rr]);
+#pragma unroll
+    for (int a = 0; a < NACC; ++a)
+#pragma unroll
+      for (int rr = 0; rr < RS; ++rr) {
+        const int r = wk * RS + rr;
+        const int row = m0 + wm0 + (a / TN) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const int col = n0 + wn0 + (a % TN) * 32 + li;
+        if (row < p.M && col < p.N) epi_store<EPI>(p, row, col, sum[a][rr], ks);
+      }
+  }
+  KH_STAMP(6);
+#ifdef KH_GEMM_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  KH_STAMP(7);
+#endif
+}
+
+// Bias half of BiasedLinearity::Update for 64 outputs, by one 256-thread workgroup riding at the end of the
+// weight-update GEMM's grid (no launch of its own): bcorr = alpha * colsum(e) + mom * bcorr ; bias -= lr * bcorr.
+// The sums are taken exactly like bias_update_kernel's (16 interleaved row groups, combined in order 0..15),
+// so both give the same bits.
+__device__ __forceinline__ void bias_update_tile(const GemmParams &p, float *lds, int tile) {
+  const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;  // q = 0..3: takes row groups q, q+4, q+8, q+12
+  const int c = tile * 64 + lane;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  if (c < p.M) {
+    const float *e = p.A + c;
+    // 8 rows of each of this thread's 4 row groups per trip: 32 independent loads in flight, then the adds in
+    // row order (the order fixes the bits)
+    for (int r0 = q; r0 < p.K; r0 += 16 * 8) {
+      float x[4][8];
+#pragma unroll
+      for (int v = 0; v < 4; ++v)
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int r = r0 + 4 * v + 16 * u;
+          x[v][u] = (r < p.K) ? e[(size_t)r * p.lda] : 0.f;
+        }
+#pragma unroll
+      for (int v = 0; v < 4; ++v)
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (r0 + 4 * v + 16 * u < p.K) acc[v] += x[v][u];
+    }
+  }
+#pragma unroll
+  for (int v = 0; v < 4; ++v) lds[(q + 4 * v) * 64 + lane] = acc[v];
+  __syncthreads();
+  if (q == 0 && c < p.M) {
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) t += lds[i * 64 + lane];
+    float bc = p.alpha * t;
+    if (p.mom != 0.f) bc += p.mom * p.bcorr[c];
+    if (p.bcorr) p.bcorr[c] = bc;
+    p.bias_io[c] = -p.lr * bc + p.bias_io[c];
+  }
+}
+
+template <int BM, int BN, int BK, int WK, bool A_KMAJOR, bool B_KMAJOR, int EPI, bool VEC>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
+  __shared__ __attribute__((aligned(16))) float lds[gemm_lds_floats<BM, BN, BK, WK, A_KMAJOR, B_KMAJOR>()];
+  if constexpr (EPI == EPI_UPDATE) {
+    static_assert(gemm_lds_floats<BM, BN, BK, WK, A_KMAJOR, B_KMAJOR>() >= 16 * 64, "bias tile needs 1024 floats");
+    const int ntile = (int)gridDim.x - p.bias_tiles;
+    if ((int)blockIdx.x >= ntile) bias_update_tile(p, lds, blockIdx.x - ntile);
+    else gemm_tile<BM, BN, BK, WK, A_KMAJOR, B_KMAJOR, EPI, VEC>(p, lds, blockIdx.x, ntile);
+  } else {
+    gemm_tile<BM, BN, BK, WK, A_KMAJOR, B_KMAJOR, EPI, VEC>(p, lds, blockIdx.x, gridDim.x);
+  }
+}
+
+// ---- sum of split-K slabs + the element-wise step that follows the GEMM ------------------------
+template <int EPI, int VEC>
+__global__ __launch_bounds__(256) void slab_reduce_kernel(GemmParams p, const float *slabs, int ld_slab) {
+  const int c = (blockIdx.x * 256 + threadIdx.x) * VEC;
+  if (c >= p.N) return;
+  for (int r = blockIdx.y; r < p.M; r += gridDim.y) {
+    float acc[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
+    const float *src = slabs + (size_t)r * ld_slab + c;
+    for (int s = 0; s < p.splitk; ++s) {
+      if (VEC == 4) {
+        const float4 v = *reinterpret_cast<const float4 *>(src + (size_t)s * p.slab_stride);
+        acc[0] += v.x; acc[1] += v.y; acc[2] += v.z; acc[3] += v.w;
+      } else {
+        acc[0] += src[(size_t)s * p.slab_stride];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < VEC; ++i)
+      if (c + i < p.N) epi_store<EPI>(p, r, c + i, epi_value<EPI>(p, acc[i], epi_aux<EPI>(p, r, c + i)), 0);
+  }
+}
+
+template <int BM, int BN, int WK, bool AK, bool BK_, int EPI>
+void launch_cfg(hipStream_t st, const GemmParams &p, bool vec) {
+  const int nblk = p.tiles_m * p.tiles_n * p.splitk + (EPI == EPI_UPDATE ? p.bias_tiles : 0);
+  if (vec)
+    hipLaunchKernelGGL((gemm_kernel<BM, BN, kBK, WK, AK, BK_, EPI, true>), dim3(nblk), dim3(256), p.dyn_lds, st, p);
+  else
+    hipLaunchKernelGGL((gemm_kernel<BM, BN, kBK, WK, AK, BK_, EPI, false>), dim3(nblk), dim3(256), p.dyn_lds, st, p);
+}
+
+template <bool AK, bool BK_, int EPI>
+void launch_tiles(hipStream_t st, const GemmParams &p, int cfg, bool vec) {
+  constexpr bool kWaveK = (EPI != EPI_UPDATE && EPI != EPI_RBM);  // the planner never picks 4, 5 for those
+  switch (cfg) {
+    case 0: launch_cfg<64, 64, 1, AK, BK_, EPI>(st, p, vec); break;
+    case 1: launch_cfg<128, 64, 1, AK, BK_, EPI>(st, p, vec); break;
+    case 2: launch_cfg<64, 128, 1, AK, BK_, EPI>(st, p, vec); break;
+    case 3: launch_cfg<128, 128, 1, AK, BK_, EPI>(st, p, vec); break;
+    case 4:
+      if constexpr (kWaveK) launch_cfg<32, 64, 2, AK, BK_, EPI>(st, p, vec);
+      break;
+    default:
+      if constexpr (kWaveK) launch_cfg<32, 32, 4, AK, BK_, EPI>(st, p, vec);
+      break;
+  }
+}
+
+template <int EPI>
+void launch_layout(hipStream_t st, const GemmParams &p, int cfg, bool vec, bool a_kmajor, bool b_kmajor) {
+  if (a_kmajor && b_kmajor) launch_tiles<true, true, EPI>(st, p, cfg, vec);
+  else if (a_kmajor && !b_kmajor) launch_tiles<true, false, EPI>(st, p, cfg, vec);
+  else if (!a_kmajor && b_kmajor) launch_tiles<false, true, EPI>(st, p, cfg, vec);
+  else launch_tiles<false, false, EPI>(st, p, cfg, vec);
+}
+
+template <int EPI>
+void launch_reduce(hipStream_t st, const GemmParams &p, const float *slabs, int ld_slab) {
+  const bool vec = (ld_slab % 4 == 0) && (p.slab_stride % 4 == 0);
+  const int per = vec ? 4 : 1;
+  int gx = (p.N + 256 * per - 1) / (256 * per);
+  int gy = p.M;
+  const int cap = 8192 / (gx > 0 ? gx : 1);
+  if (gy > cap) gy = cap < 1 ? 1 : cap;
+  if (vec)
+    hipLaunchKernelGGL((slab_reduce_kernel<EPI, 4>), dim3(gx, gy), dim3(256), 0, st, p, slabs, ld_slab);
+  else
+    hipLaunchKernelGGL((slab_reduce_kernel<EPI, 1>), dim3(gx, gy), dim3(256), 0, st, p, slabs, ld_slab);
+}
+
+
+#endif  // KHG_DEFINE_KERNELS
+
+}  // namespace khg
+#endif  // KALDI_AMD_CSRC_HIP_GEMM_KERNEL_H_

@@ -76,6 +76,21 @@ class BiasedLinearity : public UpdatableComponent {
   }
 
   void Update(const CuMatrix<BaseFloat> &input, const CuMatrix<BaseFloat> &err) {
+    if (l1_penalty_ == 0.0 && !double_buffer_) {
+      // the whole of nnet-biasedlinearity.h:71-102 (minus the L1 shrink) in one launch, weights in place
+      CuProfileScope p("BiasedLinearity::Update");
+      const int32 n = input.NumRows();
+      KALDI_ASSERT(err.NumRows() == n && err.NumCols() == output_dim_ && input.NumCols() == input_dim_);
+      const BaseFloat gscale = average_grad_ ? 1.0 / n : 1.0;
+      const BaseFloat l2 = (l2_penalty_ != 0.0) ? learn_rate_ * l2_penalty_ * n : 0.0;
+      CU_SAFE_CALL(hipF_affine_update_fused(S(), n, output_dim_, input_dim_, err.Data(), err.Stride(), input.Data(),
+                                            input.Stride(), gscale, momentum_, learn_rate_, l2, linearity_.Data(),
+                                            linearity_.Stride(), linearity_.Data(), linearity_.Stride(),
+                                            KeepCorr() ? linearity_corr_.Data() : NULL, linearity_corr_.Stride(),
+                                            bias_.Data(), KeepCorr() ? bias_corr_.Data() : NULL));
+      if (l2_upper_bound_ > 0.0) linearity_.ApplyRowL2UpperBound(l2_upper_bound_);
+      return;
+    }
     UpdateWeights(input, err);
     UpdateBias(err);
   }

@@ -171,7 +171,14 @@ void Nnet::Backpropagate(const CuMatrix<BaseFloat> &in_err, CuMatrix<BaseFloat> 
   // weights.  The side stream is joined back before returning: callers keep seeing one in-order
   // stream.
   CuDevice &dev = CuDevice::Instantiate();
-  const bool overlap = overlap_ && !dev.Profiling();
+  // Single GPU: everything stays on the main stream, in the reference's order.  Measured on the
+  // Switchboard-sized net: the update GEMMs fill the GPU on their own, and running them on a second stream
+  // beside the back-propagation cost more (event packets in the main stream's queue, two kernels halving each
+  // other's occupancy) than the gaps they filled were worth: 0.747 -> 0.715 ms per step without the streams,
+  // and each layer's bias update rides in its weight update's launch.  The update streams remain for
+  // data-parallel training, where they carry the communication.
+  static const bool force_overlap = getenv("KALDI_AMD_OVERLAP_UPDATES") != NULL;  // for A/B measurements
+  const bool overlap = overlap_ && !dev.Profiling() && (dp_ranks_ > 1 || force_overlap);
   if (overlap && static_cast<int32>(layer_events_.size()) < L) layer_events_.resize(L, NULL);
   bool side_used = false, aux_used = false;
   // to be called before the back-propagation of layer i is queued

@@ -475,6 +475,39 @@ def test_affine_forward_backward_update(hip, N, O_, I):
                 np.testing.assert_allclose(bcorr.numpy()[0], layer.b_corr, rtol=1e-4, atol=1e-7)
 
 
+@pytest.mark.parametrize("N,O_,I", [(256, 2048, 1320), (256, 1483, 1024), (37, 50, 24), (300, 130, 72), (1, 65, 8)])
+@pytest.mark.parametrize("mom", [0.0, 0.9])
+def test_affine_update_fused_equals_halves(hip, N, O_, I, mom):
+    """hipF_affine_update_fused (weight pass + bias pass in one launch, the bias sums taken by extra workgroups at
+    the end of the gradient GEMM's grid) against hipF_affine_update_weights + hipF_affine_update_bias: same bits,
+    into a second weight buffer and in place, outputs that are no multiple of the tile (ragged last bias tile)."""
+    h = hip
+    x, e = rnd((N, I), 70), rnd((N, O_), 71, 0.01)
+    W, b = rnd((O_, I), 72, 0.1), rnd((O_,), 73, 0.5)
+    c0, bc0 = rnd((O_, I), 74, 0.01), rnd((O_,), 75, 0.01)
+    dx, de = dev(h, x), dev(h, e)
+    lr, l2, g = f32(0.008), f32(1e-4), f32(1.0 / N)
+    # reference: the two halves, weights into a second buffer
+    Wa, Wa2, ba = dev(h, W), dev(h, np.zeros_like(W)), dev(h, b, False)
+    ca, bca = dev(h, c0), dev(h, bc0, False)
+    h.call("hipF_affine_update_weights", None, N, O_, I, de.ptr, de.stride, dx.ptr, dx.stride, g, f32(mom), lr, l2,
+           Wa.ptr, Wa.stride, Wa2.ptr, Wa2.stride, ca.ptr if mom else None, ca.stride)
+    h.call("hipF_affine_update_bias", None, N, O_, de.ptr, de.stride, g, f32(mom), lr, ba.ptr, bca.ptr if mom else None)
+    for in_place in (False, True):
+        Wb, Wb2, bb = dev(h, W), dev(h, np.zeros_like(W)), dev(h, b, False)
+        cb, bcb = dev(h, c0), dev(h, bc0, False)
+        out = Wb if in_place else Wb2
+        h.call("hipF_affine_update_fused", None, N, O_, I, de.ptr, de.stride, dx.ptr, dx.stride, g, f32(mom), lr, l2,
+               Wb.ptr, Wb.stride, out.ptr, out.stride, cb.ptr if mom else None, cb.stride, bb.ptr,
+               bcb.ptr if mom else None)
+        assert np.array_equal(out.numpy(), Wa2.numpy())
+        assert np.array_equal(bb.numpy(), ba.numpy())
+        if mom:
+            assert np.array_equal(cb.numpy(), ca.numpy()) and np.array_equal(bcb.numpy(), bca.numpy())
+        if not in_place:
+            assert np.array_equal(Wb.numpy(), W)   # the old weights are only read
+
+
 @pytest.mark.parametrize("N,O_,I", [(256, 1483, 1024), (256, 9000, 2048), (37, 50, 24), (64, 5000, 64), (64, 12000, 128)])
 def test_affine_forward_xent_equals_two_calls(hip, N, O_, I):
     """The fused output layer (GEMM + softmax + Xent::EvalVec) against hipF_affine_forward(softmax) followed by
