@@ -90,40 +90,63 @@ def write_rbm(path, vis, hid, vis_type, hid_type, seed):
         f.write(b"FV " + i32(hid) + np.zeros(hid, "<f4").tobytes())
 
 
-def cpu_baseline(dims, model_path, tmp, frames=4096):
-    """The reference's own nnet-train-xent-hardlab-frmshuff (built from /root/reference into
-    oracle/_ref with HAVE_CUDA off, BLAS = OpenBLAS) on `frames` synthetic frames of the same
-    workload; throughput from its compute loop wall time.  Falls back to the numpy oracle."""
+def usable_cpus():
+    """CPUs this process may run on: the scheduler affinity, capped by the cgroup's CPU quota and by
+    OMP_NUM_THREADS (the GPU boxes export the share of the machine that belongs to one GPU there)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    omp = int(os.environ.get("OMP_NUM_THREADS", "0"))
+    return min(n, omp) if omp > 0 else n
+
+
+def cpu_baseline(dims, model_path, tmp):
+    """The reference's own nnet-train-xent-hardlab-frmshuff (built from /root/reference into oracle/_ref with
+    HAVE_CUDA off, BLAS = OpenBLAS) on synthetic frames of the same workload: 32,768 frames with one BLAS thread
+    per usable CPU, and 4,096 frames with a single thread; throughput = the tool's own fps line (its main loop:
+    archive reading, cache, training; model load and write excluded).  Falls back to the numpy oracle."""
     exe = os.path.join(ROOT, "oracle", "_ref", "bin", "nnet-train-xent-hardlab-frmshuff")
-    cores = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, os.cpu_count() or 1)
+    cores = usable_cpus()
     rs = np.random.RandomState(11)
-    nutt = max(1, frames // 512)
     from oracle import nnet1_oracle as O
-    utts = [("utt%03d" % i, rs.standard_normal((512, dims[0])).astype(np.float32)) for i in range(nutt)]
-    alis = [(k, rs.randint(0, dims[-1], 512)) for k, _ in utts]
-    sample = "%d frames (%d utterances x 512), bunch %d, same model" % (nutt * 512, nutt, BUNCH)
-    if os.path.exists(exe):
+
+    def run_tool(frames, threads):
+        nutt = max(1, frames // 512)
+        utts = [("utt%03d" % i, rs.standard_normal((512, dims[0])).astype(np.float32)) for i in range(nutt)]
+        alis = [(k, rs.randint(0, dims[-1], 512)) for k, _ in utts]
         fa, aa = os.path.join(tmp, "cpu_feats.ark"), os.path.join(tmp, "cpu_ali.ark")
         open(fa, "wb").write(O.write_matrix_ark(utts))
         open(aa, "wb").write(O.write_int32_vector_ark(alis))
-        env = dict(os.environ, OPENBLAS_NUM_THREADS=str(cores), OMP_NUM_THREADS=str(cores))
+        env = dict(os.environ, OPENBLAS_NUM_THREADS=str(threads), OMP_NUM_THREADS=str(threads))
         t0 = time.time()
-        r = subprocess.run([exe, "--bunchsize=%d" % BUNCH, "--cachesize=%d" % (nutt * 512), "--randomize=false",
+        r = subprocess.run([exe, "--bunchsize=%d" % BUNCH, "--cachesize=%d" % min(nutt * 512, 32768), "--randomize=false",
                             "--binary=true", "ark:" + fa, "ark:" + aa, model_path, os.path.join(tmp, "cpu_out.nnet")],
                            stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
         wall = time.time() - t0
-        err = r.stderr.decode()
-        m = re.search(r"TRAINING FINISHED (\S+)s, fps(\S+),", err)
-        if r.returncode == 0 and m:
-            # the tool's own fps covers its whole main loop (archive reading included), as the recipes log it
-            return dict(value=float(m.group(2)), unit="frames/s", cores=cores, kind="reference",
-                        sample=sample + "; tool's own fps line, wall %.1fs incl. model load/write" % wall,
-                        blas="OpenBLAS (scipy), %d threads" % cores)
+        m = re.search(r"TRAINING FINISHED (\S+)s, fps(\S+),", r.stderr.decode())
+        if r.returncode != 0 or not m:
+            return None
+        return dict(fps=float(m.group(2)), loop_s=float(m.group(1)), wall_s=round(wall, 1), frames=nutt * 512)
+
+    if os.path.exists(exe):
+        many = run_tool(32768, cores)
+        one = run_tool(4096, 1) if many else None
+        if many and one:
+            return dict(value=many["fps"], unit="frames/s", cores=cores, kind="reference",
+                        sample="%d frames (utterances of 512), bunch %d, same model; the tool's own fps line "
+                               "(main loop %.1f s of %.1f s wall)" % (many["frames"], BUNCH, many["loop_s"], many["wall_s"]),
+                        blas="OpenBLAS (scipy), %d threads" % cores,
+                        one_thread=dict(value=one["fps"], cores=1, sample="%d frames, main loop %.1f s" % (one["frames"], one["loop_s"])))
     # numpy restatement of the same step
     layers = O.read_nnet(open(model_path, "rb").read())
     net = O.Nnet(layers)
     net.set_train_opts(0.008)
-    x, t = utts[0][1][:BUNCH], np.asarray(alis[0][1][:BUNCH])
+    x = rs.standard_normal((BUNCH, dims[0])).astype(np.float32)
+    t = rs.randint(0, dims[-1], BUNCH)
     t0 = time.time()
     n = 0
     while time.time() - t0 < 10.0:
@@ -234,6 +257,28 @@ def main():
         if world > 1:
             dist.barrier()
 
+    # Roofline of the dominant kernel, measured first: the same steps with every GEMM launch bracketed by HIP
+    # events on the stream it is queued on (a pass of its own: the event markers must not sit inside the timed
+    # region).  This pass also takes the GPU out of its idle clock state: from idle the shader clock needs
+    # ~13-20 ms of load to climb from 2.14 to 2.40 GHz (tools/clock_ramp.hip), which is most of a 20-step run.
+    roof_steps = max(30, min(args.steps, 50))
+    for i in range(40):
+        step(i)   # code objects, workspaces, first-touch, and ~28 ms of load: the clock is up when the events start
+    fence()
+    h.call("hipK_gemm_timing", 1)
+    t1 = time.perf_counter()
+    for i in range(roof_steps):
+        step(i)
+    cap = roof_steps * 64
+    sp_start, sp_dur, sp_gf = (ctypes.c_double * cap)(), (ctypes.c_double * cap)(), (ctypes.c_double * cap)()
+    sp_n = ctypes.c_int()
+    h.call("hipK_gemm_timing_spans", sp_start, sp_dur, sp_gf, cap, ctypes.byref(sp_n))
+    ms, busy, launches, fl = ctypes.c_double(), ctypes.c_double(), ctypes.c_longlong(), ctypes.c_double()
+    h.call("hipK_gemm_timing_read", ctypes.byref(ms), ctypes.byref(busy), ctypes.byref(launches), ctypes.byref(fl))
+    roof_wall = time.perf_counter() - t1
+    h.call("hipK_gemm_timing", 0)
+    fence()
+
     for i in range(args.warmup):
         step(i)
     fence()
@@ -253,21 +298,26 @@ def main():
     done = sum(frames_of(i) for i in range(args.steps))  # frames of this rank inside the timed region
     value = world * done / elapsed
 
-    # Roofline of the dominant kernel: the same steps once more with every GEMM launch bracketed by
-    # HIP events on the stream it is queued on (a pass of its own: the event markers would
-    # otherwise sit inside the timed region).  Update GEMMs run on a second stream beside the
-    # backward GEMMs, so two numbers come back: the sum of the launch durations (what a kernel
-    # trace's per-kernel averages add up to) and the time during which at least one GEMM ran.
-    roof_steps = min(args.steps, 50)
-    h.call("hipK_gemm_timing", 1)
-    t1 = time.perf_counter()
-    for i in range(roof_steps):
-        step(i)
-    ms, busy, launches, fl = ctypes.c_double(), ctypes.c_double(), ctypes.c_longlong(), ctypes.c_double()
-    h.call("hipK_gemm_timing_read", ctypes.byref(ms), ctypes.byref(busy), ctypes.byref(launches), ctypes.byref(fl))
-    roof_wall = time.perf_counter() - t1
-    h.call("hipK_gemm_timing", 0)
-    fence()
+    # per kernel class: on one GPU the GEMM launches of a step come one after another in a fixed order --
+    # forward layer by layer, then top-down back-propagation / update pairs, the bottom layer's update last
+    per_step = sp_n.value // roof_steps if roof_steps else 0
+    classes = {}
+    nl = len(dims) - 1
+    if kind == "train" and world == 1 and per_step == 3 * nl - 1 and sp_n.value == per_step * roof_steps:
+        for k in range(sp_n.value):
+            pos = k % per_step
+            if pos < nl:
+                name = "forward (NT), " + ("output layer: split-K slabs for the softmax kernel" if pos == nl - 1
+                                           else "hidden layer: bias + sigmoid epilogue")
+            else:
+                j = pos - nl
+                upd = (j % 2 == 1) or pos == per_step - 1
+                name = ("weight update (TN): SGD step in the epilogue, bias in the launch" if upd
+                        else "back-propagation (NN): y(1-y) epilogue") + (", output layer" if j < 2 else ", hidden layer")
+            c = classes.setdefault(name, [0, 0.0, 0.0])
+            c[0] += 1
+            c[1] += sp_dur[k] * 1e3
+            c[2] += sp_gf[k]
 
     if rank == 0:
         fpf = flops_per_frame(dims, kind)
@@ -292,16 +342,26 @@ def main():
                        "parallelism": ("single" if world == 1 else "dp%d" % world if kind == "train" else "replicas%d" % world),
                        "flops_per_frame": fpf,
                        "pct_fp32_mfma_peak_end_to_end": round(100.0 * value * fpf / world / (F32_MFMA_PEAK_TFLOPS * 1e12), 2)},
-            "roofline": {"bound": "mfma", "kernel": "gemm_kernel (fp32 v_mfma_f32_32x32x2_f32, all layouts)",
-                         "achieved": round(achieved, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+            # frac = algorithmic FLOPs of the GEMM launches / summed launch durations / peak: what the per-kernel
+            # averages of a rocprofv3 kernel trace of this command reproduce (profiles/); on one GPU the launches
+            # of a step run one after another, so this is also FLOPs over the time a GEMM kernel is running
+            "roofline": {"bound": "mfma", "kernel": "gemm_kernel (fp32 v_mfma_f32_32x32x2_f32, all instantiations)",
+                         "achieved": round(per_launch, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(per_launch / F32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
                          "launches_per_step": launches.value / roof_steps,
-                         "gemm_busy_ms_per_step": round(busy.value / roof_steps, 4),
-                         "gemm_launch_ms_sum_per_step": round(ms.value / roof_steps, 4),
                          "avg_launch_us": round(ms.value / max(launches.value, 1) * 1e3, 2),
-                         "achieved_per_launch_sum": round(per_launch, 2),
+                         "gflop_per_launch": round(fl.value / max(launches.value, 1) * 1e-9, 3),
+                         "gemm_launch_ms_sum_per_step": round(ms.value / roof_steps, 4),
+                         "gemm_busy_ms_per_step": round(busy.value / roof_steps, 4),
+                         "achieved_over_busy_time": round(achieved, 2),
                          "flops_per_step": fl.value / roof_steps,
-                         "instrumented_pass_ms_per_step": round(roof_wall / roof_steps * 1e3, 4)},
+                         "instrumented_pass_ms_per_step": round(roof_wall / roof_steps * 1e3, 4),
+                         "per_kernel": [{"kernel": k, "launches_per_step": round(v[0] / roof_steps, 2),
+                                         "avg_launch_us": round(v[1] / v[0], 2), "gflop_per_launch": round(v[2] / v[0], 3),
+                                         "achieved": round(v[2] / v[1] * 1e3 if v[1] else 0.0, 2),
+                                         "frac": round(v[2] / v[1] * 1e3 / F32_MFMA_PEAK_TFLOPS if v[1] else 0.0, 4)}
+                                        for k, v in sorted(classes.items())]},
+            "order": "40 set-up steps (first touch; the clock climbs out of its idle state), %d steps with GEMM launches bracketed by events (roofline), %d warm-up steps, %d timed steps" % (roof_steps, args.warmup, args.steps),
             "check": {"frames": frames, "mean_xent": round(loss / max(frames, 1), 4)},
         }
         if world == 1 and not args.no_cpu_baseline and kind == "train":

@@ -280,7 +280,7 @@ int hipF_affine_update(khStream_t s, int32_t N, int32_t O, int32_t I, const floa
 
 /* hipF_affine_update with the new weights written to W_out (W_in itself, or a second O x I buffer as in
  * hipF_affine_update_weights): weight pass and bias pass in ONE launch -- the bias sums are taken by a few
- * extra workgroups at the end of the gradient GEMM's grid.  Same bits as the two halves below. */
+ * extra workgroups at the start of the gradient GEMM's grid.  Same bits as the two halves below. */
 int hipF_affine_update_fused(khStream_t s, int32_t N, int32_t O, int32_t I, const float *e, int32_t lde,
                              const float *in, int32_t ldin, float gscale, float momentum, float lr, float l2,
                              const float *W_in, int32_t ldw_in, float *W_out, int32_t ldw_out, float *corr,

@@ -579,7 +579,7 @@ KH_EXPORT int hipF_affine_update_fused(khStream_t s, int32_t N, int32_t O, int32
   p.ldwout = ldw_out;
   p.bias_io = bias;
   p.bcorr = bcorr;
-  p.bias_tiles = (O + 63) / 64;  // ride at the end of the GEMM's grid
+  p.bias_tiles = (O + 63) / 64;  // ride at the start of the GEMM's grid
   return run_gemm<EPI_UPDATE>(s, false, false, p, /*allow_split=*/false);
 }
 

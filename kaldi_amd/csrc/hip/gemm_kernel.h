@@ -46,7 +46,7 @@ struct GemmParams {
   float lr, l2, mom;
   int act;
   int dyn_lds;     // extra LDS bytes to request at launch (caps how many workgroups share a compute unit)
-  // EPI_UPDATE only: the bias half of the update, done by `bias_tiles` extra workgroups at the end of the grid
+  // EPI_UPDATE only: the bias half of the update, done by `bias_tiles` extra workgroups at the start of the grid
   // (bias_io -= lr * (alpha * colsum(A) + mom * bcorr); A is the error matrix, K x M as stored)
   float *bias_io;
   float *bcorr;
@@ -704,7 +704,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams &p, float *lds, const
 #endif
 }
 
-// Bias half of BiasedLinearity::Update for 64 outputs, by one 256-thread workgroup riding at the end of the
+// Bias half of BiasedLinearity::Update for 64 outputs, by one 256-thread workgroup riding at the start of the
 // weight-update GEMM's grid (no launch of its own): bcorr = alpha * colsum(e) + mom * bcorr ; bias -= lr * bcorr.
 // The sums are taken exactly like bias_update_kernel's (16 interleaved row groups, combined in order 0..15),
 // so both give the same bits.
@@ -751,9 +751,14 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
   __shared__ __attribute__((aligned(16))) float lds[gemm_lds_floats<BM, BN, BK, WK, A_KMAJOR, B_KMAJOR>()];
   if constexpr (EPI == EPI_UPDATE) {
     static_assert(gemm_lds_floats<BM, BN, BK, WK, A_KMAJOR, B_KMAJOR>() >= 16 * 64, "bias tile needs 1024 floats");
-    const int ntile = (int)gridDim.x - p.bias_tiles;
-    if ((int)blockIdx.x >= ntile) bias_update_tile(p, lds, blockIdx.x - ntile);
-    else gemm_tile<BM, BN, BK, WK, A_KMAJOR, B_KMAJOR, EPI, VEC>(p, lds, blockIdx.x, ntile);
+    // the bias workgroups come first (p.bias_tiles rounded up to a multiple of 8 in the grid, so that the tile
+    // index below stays congruent to blockIdx.x modulo 8): they are short and finish while the GEMM tiles run
+    const int nbias = (p.bias_tiles + 7) & ~7;
+    if ((int)blockIdx.x < nbias) {
+      if ((int)blockIdx.x < p.bias_tiles) bias_update_tile(p, lds, blockIdx.x);
+    } else {
+      gemm_tile<BM, BN, BK, WK, A_KMAJOR, B_KMAJOR, EPI, VEC>(p, lds, blockIdx.x - nbias, (int)gridDim.x - nbias);
+    }
   } else {
     gemm_tile<BM, BN, BK, WK, A_KMAJOR, B_KMAJOR, EPI, VEC>(p, lds, blockIdx.x, gridDim.x);
   }
@@ -785,7 +790,7 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(GemmParams p, const fl
 
 template <int BM, int BN, int WK, bool AK, bool BK_, int EPI>
 void launch_cfg(hipStream_t st, const GemmParams &p, bool vec) {
-  const int nblk = p.tiles_m * p.tiles_n * p.splitk + (EPI == EPI_UPDATE ? p.bias_tiles : 0);
+  const int nblk = p.tiles_m * p.tiles_n * p.splitk + (EPI == EPI_UPDATE ? ((p.bias_tiles + 7) & ~7) : 0);
   if (vec)
     hipLaunchKernelGGL((gemm_kernel<BM, BN, kBK, WK, AK, BK_, EPI, true>), dim3(nblk), dim3(256), p.dyn_lds, st, p);
   else

@@ -84,15 +84,30 @@ class Matrix {
     if (!os.good()) KALDI_ERR << "Failed to write matrix to stream";
   }
 
+  /// The header of a binary matrix ("FM" | "DM", rows, cols: kaldi-matrix.cc:1043-1062): after it the stream
+  /// stands at the first of rows * cols * elem_bytes payload bytes, which ReadBinaryPayload reads and a caller
+  /// that only wanted the size may skip.
+  static void ReadBinaryHeader(std::istream &is, std::string *tok, int32 *rows, int32 *cols, size_t *elem_bytes) {
+    ReadToken(is, true, tok);
+    if (*tok != "FM" && *tok != "DM") KALDI_ERR << "Failed to read matrix from stream: expected FM or DM, got " << *tok;
+    ReadBasicType(is, true, rows);
+    ReadBasicType(is, true, cols);
+    if (*rows < 0 || *cols < 0) KALDI_ERR << "Failed to read matrix from stream: negative size";
+    *elem_bytes = (*tok == "FM") ? 4 : 8;
+  }
   void Read(std::istream &is, bool binary) {
     if (binary) {
       std::string tok;
-      ReadToken(is, binary, &tok);
-      if (tok != "FM" && tok != "DM") KALDI_ERR << "Failed to read matrix from stream: expected FM or DM, got " << tok;
       int32 r, c;
-      ReadBasicType(is, binary, &r);
-      ReadBasicType(is, binary, &c);
-      if (r < 0 || c < 0) KALDI_ERR << "Failed to read matrix from stream: negative size";
+      size_t elem;
+      ReadBinaryHeader(is, &tok, &r, &c, &elem);
+      ReadBinaryPayload(is, tok, r, c);
+      return;
+    }
+    ReadText(is);
+  }
+  void ReadBinaryPayload(std::istream &is, const std::string &tok, int32 r, int32 c) {
+    {
       rows_ = r;
       cols_ = c;
       const size_t n = static_cast<size_t>(r) * c;
@@ -110,8 +125,9 @@ class Matrix {
       }
       if (is.fail()) KALDI_ERR << "Failed to read matrix from stream (" << r << " x " << c << "): truncated";
       if (r == 0 || c == 0) rows_ = cols_ = 0;
-      return;
     }
+  }
+  void ReadText(std::istream &is) {
     std::string s;
     is >> s;
     if (is.fail()) KALDI_ERR << "Failed to read matrix from stream: expected \"[\", got EOF";

@@ -94,9 +94,16 @@ void Xent::GetStats(int64 *frames, int64 *correct, double *loss) {
 
 std::string Xent::Report() {
   Sync();
+  if (!soft_label_only_) return FormatReport(loss_, frames_, correct_);
   std::ostringstream oss;
   oss << "Xent:" << loss_ << " frames:" << frames_ << " err/frm:" << loss_ / frames_;
-  if (!soft_label_only_) oss << "\nFRAME_ACCURACY >> " << 100.0 * correct_ / frames_ << "% <<";
+  return oss.str();
+}
+
+std::string Xent::FormatReport(double loss, int64 frames, int64 correct) {
+  std::ostringstream oss;
+  oss << "Xent:" << loss << " frames:" << frames << " err/frm:" << loss / frames;
+  oss << "\nFRAME_ACCURACY >> " << 100.0 * correct / frames << "% <<";
   return oss.str();
 }
 

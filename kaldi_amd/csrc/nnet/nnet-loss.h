@@ -53,7 +53,11 @@ class Xent {
     *loss = stats_.Loss();
   }
 
-  std::string Report();
+std::string Report();
+  /// The report string for totals gathered elsewhere (all ranks of a data-parallel run), in the format of
+  /// Report(): nnet-loss.cc:97-105.  The recipes' scheduler takes field 3 of the FRAME_ACCURACY line.
+  static std::string FormatReport(double loss, int64 frames, int64 correct);
+  
   void Reset();
   BaseFloat GetFrameAccuracy();
   /// per-frame log-posteriors and arg-max ids of the last EvalVec call (device)

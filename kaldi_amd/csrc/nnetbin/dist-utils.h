@@ -4,8 +4,10 @@
 // The reference tools are single-GPU; with one rank everything here is a no-op.
 #ifndef KALDI_AMD_NNETBIN_DIST_UTILS_H_
 #define KALDI_AMD_NNETBIN_DIST_UTILS_H_
+#include <fcntl.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 #include <unistd.h>
 
 #include <fstream>
@@ -41,35 +43,72 @@ struct DistOptions {
   }
 };
 
+/// What tells this launch's id file from a stale one left by a launch that died: the launcher's run id where
+/// there is one (torch.distributed.run exports TORCHELASTIC_RUN_ID), the rendezvous port, and the parent
+/// process -- the ranks of one launch are children of one launcher, and a relaunch has another.
+inline std::string CommNonce() {
+  const char *run = getenv("KALDI_AMD_RUN_ID");
+  if (!run) run = getenv("TORCHELASTIC_RUN_ID");
+  const char *port = getenv("MASTER_PORT");
+  return std::string(run ? run : "-") + ":" + (port ? port : "-") + ":" + std::to_string(static_cast<long>(getppid()));
+}
+
 /// selects the GPU and, with more than one rank and need_comm, builds the RCCL communicator
-/// (a tool whose ranks never exchange data, like nnet-forward, passes need_comm = false)
+/// (a tool whose ranks never exchange data, like nnet-forward, passes need_comm = false).
+/// Rank 0 hands the RCCL id to the others through --comm-id-file: [magic | nonce | id], written to a fresh
+/// file (O_EXCL, mode 0600) and renamed into place; readers wait for a file that carries THEIR launch's nonce,
+/// so an id left behind by a killed launch is never joined.  For a multi-node run the file must be on storage
+/// every node sees, and ranks started by hand should be given a --comm-id-file of their own per launch.
 inline void DistInit(const DistOptions &o, bool need_comm = true) {
   CuDevice::Instantiate().SelectGpuId(o.gpu_id);
   if (o.num_ranks == 1 || !need_comm) return;
+  if (getenv("KALDI_AMD_COMM_LOOPBACK") != NULL) {
+    // rehearsal on one GPU: this process runs as its rank of num_ranks with the library's stand-in communicator
+    // (a sum all-reduce multiplies by num_ranks, min / max / barrier are local); exercises the multi-rank control flow
+    CU_SAFE_CALL(hipK_comm_init_loopback(o.num_ranks));
+    return;
+  }
   unsigned char id[KH_COMM_ID_BYTES];
-  const std::string tmp = o.comm_id_file + ".tmp";
+  const std::string tmp = o.comm_id_file + ".tmp." + std::to_string(static_cast<long>(getpid()));
+  const std::string nonce = CommNonce();
+  const char magic[8] = {'K', 'A', 'M', 'D', 'I', 'D', '0', '1'};
   if (o.rank == 0) {
+    unlink(o.comm_id_file.c_str());  // whatever an earlier launch left
+    unlink(tmp.c_str());
     CU_SAFE_CALL(hipK_comm_get_unique_id(id));
-    std::ofstream os(tmp.c_str(), std::ios::binary);
-    os.write(reinterpret_cast<const char *>(id), sizeof(id));
-    os.close();
-    if (!os.good() || rename(tmp.c_str(), o.comm_id_file.c_str()) != 0)
+    const int fd = open(tmp.c_str(), O_WRONLY | O_CREAT | O_EXCL, 0600);
+    if (fd < 0) KALDI_ERR << "Cannot create " << tmp << " for the communicator id";
+    const uint32 n = nonce.size();
+    bool ok = write(fd, magic, sizeof(magic)) == static_cast<ssize_t>(sizeof(magic)) &&
+              write(fd, &n, sizeof(n)) == static_cast<ssize_t>(sizeof(n)) &&
+              write(fd, nonce.data(), n) == static_cast<ssize_t>(n) &&
+              write(fd, id, sizeof(id)) == static_cast<ssize_t>(sizeof(id));
+    ok = (close(fd) == 0) && ok;
+    if (!ok || rename(tmp.c_str(), o.comm_id_file.c_str()) != 0)
       KALDI_ERR << "Cannot write the communicator id to " << o.comm_id_file;
   } else {
     bool ok = false;
     for (int tries = 0; tries < 6000 && !ok; ++tries) {  // up to 10 minutes
       std::ifstream is(o.comm_id_file.c_str(), std::ios::binary);
       if (is.good()) {
-        is.read(reinterpret_cast<char *>(id), sizeof(id));
-        ok = is.gcount() == static_cast<std::streamsize>(sizeof(id));
+        char m[8];
+        uint32 n = 0;
+        is.read(m, sizeof(m));
+        is.read(reinterpret_cast<char *>(&n), sizeof(n));
+        if (is.good() && memcmp(m, magic, sizeof(m)) == 0 && n == nonce.size()) {
+          std::string got(n, '\0');
+          is.read(&got[0], n);
+          is.read(reinterpret_cast<char *>(id), sizeof(id));
+          ok = is.gcount() == static_cast<std::streamsize>(sizeof(id)) && got == nonce;  // else: a stale file
+        }
       }
       if (!ok) usleep(100000);
     }
-    if (!ok) KALDI_ERR << "Timed out waiting for the communicator id in " << o.comm_id_file;
+    if (!ok) KALDI_ERR << "Timed out waiting for this launch's communicator id in " << o.comm_id_file;
   }
   CU_SAFE_CALL(hipK_comm_init(id, o.rank, o.num_ranks));
   CU_SAFE_CALL(hipK_comm_barrier(CuDevice::Instantiate().Stream()));
-  if (o.rank == 0) remove(o.comm_id_file.c_str());  // every rank has joined
+  if (o.rank == 0) unlink(o.comm_id_file.c_str());  // every rank has joined
 }
 
 inline void DistFinalize(const DistOptions &o, bool need_comm = true) {
@@ -89,6 +128,23 @@ inline int64 DistAllReduce(const DistOptions &o, int64 value, int op) {
   long long v = value;
   CU_SAFE_CALL(hipK_memcpy(s, dev, &v, sizeof(v), 0));
   CU_SAFE_CALL(hipK_allreduce_i64(s, dev, 1, op));
+  CU_SAFE_CALL(hipK_memcpy(s, &v, dev, sizeof(v), 1));
+  return v;
+}
+
+/// sum all-reduce of one host double; blocking
+inline double DistAllReduceSum(const DistOptions &o, double value) {
+  if (o.num_ranks == 1) return value;
+  static double *dev = NULL;
+  if (!dev) {
+    void *p = NULL;
+    CU_SAFE_CALL(hipK_malloc(&p, sizeof(double)));
+    dev = static_cast<double *>(p);
+  }
+  khStream_t s = CuDevice::Instantiate().Stream();
+  double v = value;
+  CU_SAFE_CALL(hipK_memcpy(s, dev, &v, sizeof(v), 0));
+  CU_SAFE_CALL(hipK_allreduce_sum_f64(s, dev, 1));
   CU_SAFE_CALL(hipK_memcpy(s, &v, dev, sizeof(v), 1));
   return v;
 }

@@ -70,7 +70,13 @@ int main(int argc, char *argv[]) {
     nnet_transf.SetFusion(fused);
 
     kaldi::int64 tot_t = 0;
-    PrefetchingBaseFloatMatrixReader feature_reader(feature_rspecifier);  // reads ahead on a thread of its own
+    // Every rank walks the same table and keeps the utterances the assigner gives it (the rank with the fewest
+    // frames so far), decided on each entry's header: a binary matrix of another rank is skipped unread.  The
+    // reader reads ahead on a thread of its own; the assigner is only used there.
+    ShardAssigner shard(dist.num_ranks);
+    const int32 my_rank = dist.rank;
+    PrefetchingBaseFloatMatrixReader feature_reader(
+        feature_rspecifier, [&shard, my_rank](const std::string &, int32 rows) { return shard.Assign(rows) == my_rank; });
     // writes behind on a thread of its own, which also scans every output for NaN / inf first
     AsyncBaseFloatMatrixWriter feature_writer(
         feature_wspecifier, 3, [](const std::string &key, const Matrix<BaseFloat> &m) { CheckFinite(m, "NNet output", key); });
@@ -98,11 +104,9 @@ int main(int argc, char *argv[]) {
     Timer tim;
     if (!silent) KALDI_LOG << "MLP FEEDFORWARD STARTED";
 
-    ShardAssigner shard(dist.num_ranks);
     int32 num_done = 0;
     for (; !feature_reader.Done(); feature_reader.Next()) {
       const Matrix<BaseFloat> &mat = feature_reader.Value();
-      if (shard.Assign(mat.NumRows()) != dist.rank) continue;
       CheckFinite(mat, "features", feature_reader.Key());
       feats.CopyFromMat(mat);
       nnet_transf.Feedforward(feats, &feats_transf);
@@ -123,6 +127,9 @@ int main(int argc, char *argv[]) {
     if (!feature_writer.Close()) KALDI_ERR << "Error closing the output table " << feature_wspecifier;
     if (!silent) KALDI_LOG << "MLP FEEDFORWARD FINISHED " << tim.Elapsed() << "s, fps" << tot_t / tim.Elapsed();
     if (!silent) KALDI_LOG << "Done " << num_done << " files";
+    if (!silent && dist.num_ranks > 1)
+      KALDI_LOG << "rank " << dist.rank << " of " << dist.num_ranks << ": feature payload read "
+                << feature_reader.PayloadBytesRead() << " bytes";
     if (!silent) CuDevice::Instantiate().PrintProfile();
     DistFinalize(dist, /*need_comm=*/false);
     return ((num_done > 0) ? 0 : 1);

@@ -89,7 +89,13 @@ int main(int argc, char *argv[]) {
 
     kaldi::int64 tot_t = 0;
 
-    PrefetchingBaseFloatMatrixReader feature_reader(feature_rspecifier);  // reads ahead on a thread of its own
+    // Every rank walks the same feature table and keeps the utterances the assigner gives it (the rank with the
+    // fewest frames so far), decided on each entry's header: a binary matrix that belongs to another rank is
+    // skipped unread.  The reader reads ahead on a thread of its own; the assigner is only used there.
+    ShardAssigner shard(dist.num_ranks);
+    const int32 my_rank = dist.rank;
+    PrefetchingBaseFloatMatrixReader feature_reader(
+        feature_rspecifier, [&shard, my_rank](const std::string &, int32 rows) { return shard.Assign(rows) == my_rank; });
     RandomAccessInt32VectorReader alignments_reader(alignments_rspecifier);
 
     Cache cache;
@@ -101,7 +107,6 @@ int main(int argc, char *argv[]) {
     CuMatrix<BaseFloat> feats_transf, nnet_in, nnet_out, glob_err;
     FeatureUploader uploader(cachesize);
     CuStlVector<int32> targets;
-    ShardAssigner shard(dist.num_ranks);
 
     Timer tim;
     double time_next = 0;
@@ -109,34 +114,42 @@ int main(int argc, char *argv[]) {
 
     int32 num_done = 0, num_no_alignment = 0, num_other_error = 0, num_cache = 0;
     while (1) {
-      // fill the cache with this rank's utterances
-      while (!cache.Full() && !feature_reader.Done()) {
-        std::string key = feature_reader.Key();
-        if (!alignments_reader.HasKey(key)) {
-          num_no_alignment++;
-        } else {
-          const Matrix<BaseFloat> &mat = feature_reader.Value();
-          const std::vector<int32> &alignment = alignments_reader.Value(key);
-          if ((int32)alignment.size() != mat.NumRows()) {
-            KALDI_WARN << "Alignment has wrong size " << (alignment.size()) << " vs. " << (mat.NumRows());
-            num_other_error++;
-            // step to the next utterance (the reference retried the same one forever)
-          } else if (shard.Assign(mat.NumRows()) == dist.rank) {
-            for (size_t i = 0; i < alignment.size(); ++i)
-              if (alignment[i] < 0 || alignment[i] >= nnet.OutputDim())
-                KALDI_ERR << "Alignment of " << key << " has label " << alignment[i] << " outside the network's "
-                          << nnet.OutputDim() << " outputs";
-            const CuMatrix<BaseFloat> &feats = uploader.Upload(mat);  // host -> device, beside the training
-            nnet_transf.Feedforward(feats, &feats_transf);     // optional transform
-            cache.AddData(feats_transf, alignment);
-            num_done++;
+      // fill the cache with this rank's utterances; with several ranks an error here is told to the others
+      // below instead of leaving them waiting in a collective for a rank that has gone
+      std::string fill_error;
+      try {
+        while (!cache.Full() && !feature_reader.Done()) {
+          std::string key = feature_reader.Key();
+          if (!alignments_reader.HasKey(key)) {
+            num_no_alignment++;
+          } else {
+            const Matrix<BaseFloat> &mat = feature_reader.Value();
+            const std::vector<int32> &alignment = alignments_reader.Value(key);
+            if ((int32)alignment.size() != mat.NumRows()) {
+              KALDI_WARN << "Alignment has wrong size " << (alignment.size()) << " vs. " << (mat.NumRows());
+              num_other_error++;
+              // step to the next utterance (the reference retried the same one forever)
+            } else {
+              for (size_t i = 0; i < alignment.size(); ++i)
+                if (alignment[i] < 0 || alignment[i] >= nnet.OutputDim())
+                  KALDI_ERR << "Alignment of " << key << " has label " << alignment[i] << " outside the network's "
+                            << nnet.OutputDim() << " outputs";
+              const CuMatrix<BaseFloat> &feats = uploader.Upload(mat);  // host -> device, beside the training
+              nnet_transf.Feedforward(feats, &feats_transf);     // optional transform
+              cache.AddData(feats_transf, alignment);
+              num_done++;
+            }
           }
+          Timer t_features;
+          feature_reader.Next();
+          time_next += t_features.Elapsed();
         }
-        Timer t_features;
-        feature_reader.Next();
-        time_next += t_features.Elapsed();
+      } catch (const std::exception &e) {
+        if (dist.num_ranks == 1) throw;
+        fill_error = e.what();
       }
-      if (!crossvalidate && randomize) cache.Randomize();
+      // (a rank whose shard has run dry holds nothing to shuffle: it takes part in the collectives with 0 bunches)
+      if (!crossvalidate && randomize && fill_error.empty() && cache.NumBunches() > 0) cache.Randomize();
       std::cerr << "Cache #" << ++num_cache << " " << (cache.Randomized() ? "[RND]" : "[NO-RND]")
                 << " segments: " << num_done << " frames: " << tot_t << "\n";
 
@@ -150,8 +163,12 @@ int main(int argc, char *argv[]) {
         }
         if (feature_reader.Done()) break;
       } else {
-        // every rank must take the same number of steps: agree once per cache on the bunch count
-        const int64 bunches = DistAllReduce(dist, cache.NumBunches(), 1 /*min*/);
+        // every rank must take the same number of steps: agree once per cache on the bunch count (the
+        // minimum over the ranks; -1 from a rank that failed makes every rank stop with an error)
+        const int64 bunches = DistAllReduce(dist, fill_error.empty() ? cache.NumBunches() : -1, 1 /*min*/);
+        if (bunches < 0)
+          KALDI_ERR << (fill_error.empty() ? std::string("Another rank failed while reading its data; stopping")
+                                           : "Rank " + std::to_string(dist.rank) + " failed: " + fill_error);
         for (int64 b = 0; b < bunches; ++b) {
           if (fused) cache.GetBunchView(&nnet_in, &targets);
           else cache.GetBunch(&nnet_in, &targets);
@@ -159,9 +176,11 @@ int main(int argc, char *argv[]) {
           if (!crossvalidate) nnet.Backpropagate(glob_err, NULL);
           tot_t += nnet_in.NumRows();
         }
-        // bunches this rank still holds when another rank had fewer are dropped (last cache only:
-        // full caches hold the same number everywhere)
+        // bunches this rank still holds when another rank had fewer are dropped (last cache only: full caches
+        // hold the same number everywhere), as a single process drops its last partial bunch
         while (!cache.Empty()) cache.GetBunch(&nnet_in, &targets);
+        // Stop once any rank's shard has run dry: shards are balanced by frames, so the others hold at most a few
+        // utterances more, which no round of equal steps could use.
         if (DistAllReduce(dist, feature_reader.Done() ? 1 : 0, 2 /*max*/)) break;
       }
     }
@@ -175,15 +194,23 @@ int main(int argc, char *argv[]) {
               << tot_t / tim.Elapsed() << ", feature wait " << time_next << "s";
     KALDI_LOG << "Done " << num_done << " files, " << num_no_alignment << " with no alignments, " << num_other_error
               << " with other errors.";
-    KALDI_LOG << xent.Report();
-    if (dist.num_ranks > 1) {
+    if (dist.num_ranks == 1) {
+      KALDI_LOG << xent.Report();
+    } else {
+      // One report for the whole job, on rank 0, in the reference's format (the recipes' scheduler takes the
+      // accuracy from the FRAME_ACCURACY line): frames, correct frames and loss summed over the ranks.  The other
+      // ranks log their shard without that keyword.
       int64 frames, correct;
       double loss;
       xent.GetStats(&frames, &correct, &loss);
       const int64 all_frames = DistAllReduce(dist, frames, 0), all_correct = DistAllReduce(dist, correct, 0);
-      if (dist.rank == 0)
-        KALDI_LOG << "ALL RANKS frames:" << all_frames << " FRAME_ACCURACY_ALL >> " << 100.0 * all_correct / all_frames
-                  << "% << over " << dist.num_ranks << " ranks, fps_all " << all_frames / tim.Elapsed();
+      const double all_loss = DistAllReduceSum(dist, loss);
+      KALDI_LOG << "rank " << dist.rank << " of " << dist.num_ranks << ": shard frames:" << frames << " correct:" << correct
+                << " xent:" << loss << ", feature payload read " << feature_reader.PayloadBytesRead() << " bytes";
+      if (dist.rank == 0) {
+        KALDI_LOG << "all " << dist.num_ranks << " ranks: fps " << all_frames / tim.Elapsed();
+        KALDI_LOG << Xent::FormatReport(all_loss, all_frames, all_correct);
+      }
     }
     CuDevice::Instantiate().PrintProfile();
     DistFinalize(dist);

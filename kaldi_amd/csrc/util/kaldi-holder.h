@@ -4,11 +4,14 @@
 //   basic vector : binary "\0B" int32 n, then n basic values; text: "v0 v1 ... \n"
 #ifndef KALDI_AMD_UTIL_KALDI_HOLDER_H_
 #define KALDI_AMD_UTIL_KALDI_HOLDER_H_
+#include <functional>
 #include <sstream>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "base/kaldi-common.h"
+#include "matrix/kaldi-matrix.h"
 
 namespace kaldi {
 
@@ -40,10 +43,60 @@ class KaldiObjectHolder {
       return false;
     }
   }
+  /// Read, but only if keep(rows) says so (multi-rank tools: every rank walks the same table and keeps its own
+  /// utterances).  For a binary matrix the decision is taken on the header and a payload nobody wants is skipped
+  /// unread -- a seek on a file, a discard on a pipe; anything else is read and then dropped.  *kept tells whether
+  /// Value() now holds the entry, *payload_read how many payload bytes were brought in from the stream.
+  bool ReadIf(std::istream &is, const std::function<bool(int32)> &keep, bool *kept, size_t *payload_read) {
+    bool binary;
+    if (!InitKaldiInputStream(is, &binary)) {
+      KALDI_WARN << "Reading Table object, failed reading binary header";
+      return false;
+    }
+    try {
+      if constexpr (std::is_same<T, Matrix<float> >::value || std::is_same<T, Matrix<double> >::value) {
+        if (binary) {
+          std::string tok;
+          int32 r, c;
+          size_t elem;
+          T::ReadBinaryHeader(is, &tok, &r, &c, &elem);
+          const std::streamoff bytes = static_cast<std::streamoff>(r) * c * elem;
+          *kept = keep(r);
+          if (*kept) {
+            t_.ReadBinaryPayload(is, tok, r, c);
+            *payload_read += bytes;
+          } else if (bytes > 0) {
+            const std::istream::pos_type here = is.tellg();
+            if (here != std::istream::pos_type(-1)) {
+              is.seekg(here + bytes);
+            } else {
+              is.clear();
+              is.ignore(bytes);  // not seekable: the bytes have to pass through anyway
+              *payload_read += bytes;
+            }
+            if (is.fail()) return false;
+          }
+          return true;
+        }
+      }
+      const std::istream::pos_type before = is.tellg();
+      t_.Read(is, binary);
+      const std::istream::pos_type after = is.tellg();
+      if (before != std::istream::pos_type(-1) && after != std::istream::pos_type(-1)) *payload_read += after - before;
+      *kept = keep(RowsOf(t_));
+      return true;
+    } catch (const std::exception &) {
+      KALDI_WARN << "Exception caught reading Table object";
+      return false;
+    }
+  }
   const T &Value() const { return t_; }
   void Clear() { t_ = T(); }
 
  private:
+  template <class U>
+  static auto RowsOf(const U &u) -> decltype(u.NumRows(), int32()) { return u.NumRows(); }
+  static int32 RowsOf(...) { return 0; }
   T t_;
 };
 

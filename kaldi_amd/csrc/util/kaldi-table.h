@@ -51,6 +51,16 @@ class SequentialTableReader {
   explicit SequentialTableReader(const std::string &rspecifier) : type_(kNoRspecifier), done_(true), pos_(0) {
     if (!Open(rspecifier)) KALDI_ERR << "Error constructing TableReader: rspecifier is " << rspecifier;
   }
+  /// Entries are presented only where keep(key, rows) is true (rows = NumRows() of the value); set before Open.
+  /// keep is called once per entry, in table order.  Holders that can (binary matrices) decide on the entry's
+  /// header and skip the payload of the others unread: a rank of a multi-GPU run then reads 1/N of the table.
+  typedef std::function<bool(const std::string &, int32)> Filter;
+  SequentialTableReader(const std::string &rspecifier, const Filter &keep)
+      : type_(kNoRspecifier), done_(true), pos_(0), keep_(keep) {
+    if (!Open(rspecifier)) KALDI_ERR << "Error constructing TableReader: rspecifier is " << rspecifier;
+  }
+  /// bytes of value payload brought in from the table so far (with a filter: what skipping saved shows here)
+  size_t PayloadBytesRead() const { return payload_read_; }
   bool Open(const std::string &rspecifier) {
     rspecifier_ = rspecifier;
     std::string rx;
@@ -107,6 +117,32 @@ class SequentialTableReader {
         KALDI_ERR << "TableReader: invalid archive file format: expected space after key " << key_ << ", got character "
                   << static_cast<char>(c) << ", reading " << rspecifier_;
       if (c != '\n') is.get();  // a bare newline belongs to an empty text-mode value
+      if (keep_) {
+        for (;;) {
+          bool kept = false;
+          const std::string key = key_;
+          if (!holder_.ReadIf(is, [&](int32 rows) { return keep_(key, rows); }, &kept, &payload_read_)) {
+            if (opts_.permissive) {
+              KALDI_WARN << "TableReader: error reading object for key " << key_ << "; ignoring the rest of the archive";
+              done_ = true;
+              return;
+            }
+            KALDI_ERR << "TableReader: failed to read object from archive, key " << key_ << ", reading " << rspecifier_;
+          }
+          if (kept) return;
+          is.clear();
+          is >> key_;
+          if (is.eof() || is.fail()) {
+            done_ = true;
+            return;
+          }
+          const int c2 = is.peek();
+          if (c2 != ' ' && c2 != '\t' && c2 != '\n')
+            KALDI_ERR << "TableReader: invalid archive file format: expected space after key " << key_ << ", reading "
+                      << rspecifier_;
+          if (c2 != '\n') is.get();
+        }
+      }
       if (!holder_.Read(is)) {
         if (opts_.permissive) {
           KALDI_WARN << "TableReader: error reading object for key " << key_ << "; ignoring the rest of the archive";
@@ -120,7 +156,17 @@ class SequentialTableReader {
         const std::pair<std::string, std::string> &e = script_[pos_++];
         key_ = e.first;
         Input in;
-        if (in.OpenTextMode(e.second) && holder_.Read(in.Stream())) return;
+        if (keep_) {
+          bool kept = false;
+          const std::string key = key_;
+          if (in.OpenTextMode(e.second) &&
+              holder_.ReadIf(in.Stream(), [&](int32 rows) { return keep_(key, rows); }, &kept, &payload_read_)) {
+            if (kept) return;
+            continue;
+          }
+        } else if (in.OpenTextMode(e.second) && holder_.Read(in.Stream())) {
+          return;
+        }
         if (!opts_.permissive) KALDI_ERR << "TableReader: failed to load object from " << PrintableRxfilename(e.second);
         KALDI_WARN << "TableReader: skipping key " << key_ << ", cannot read " << PrintableRxfilename(e.second);
       }
@@ -135,6 +181,8 @@ class SequentialTableReader {
   bool done_;
   std::vector<std::pair<std::string, std::string> > script_;
   size_t pos_;
+  Filter keep_;
+  size_t payload_read_ = 0;
 };
 
 // ---- sequential reader with a read-ahead thread ---------------------------------------------
@@ -152,6 +200,15 @@ class PrefetchingTableReader {
     thread_ = std::thread(&PrefetchingTableReader::Run, this);
     Pop();
   }
+  /// with an entry filter (see SequentialTableReader); keep runs on the read-ahead thread
+  PrefetchingTableReader(const std::string &rspecifier, const typename SequentialTableReader<Holder>::Filter &keep,
+                         size_t max_ahead = 64)
+      : reader_(rspecifier, keep), max_ahead_(max_ahead), stop_(false), finished_(false), have_(false) {
+    thread_ = std::thread(&PrefetchingTableReader::Run, this);
+    Pop();
+  }
+  /// payload bytes read so far (only settled once Done())
+  size_t PayloadBytesRead() const { return reader_.PayloadBytesRead(); }
   ~PrefetchingTableReader() {
     {
       std::lock_guard<std::mutex> l(mu_);

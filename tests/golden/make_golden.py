@@ -332,13 +332,79 @@ def gen_siblings(tmp):
     print("siblings_small: %d arrays" % len(fix))
 
 
+def gen_transform(tmp):
+    """--feature-transform in the three tools (nnetbin/nnet-forward.cc:66-75,127-131,
+    nnet-train-xent-hardlab-frmshuff.cc:148, rbm-train-cd1-frmshuff.cc:117): a transform network
+    <expand> (+-5 frames) -> <copy> (a permuted subset of the spliced columns, 1-based on disk) ->
+    <biasedlinearity> <sigmoid>, as the stacked-RBM recipe builds it (egs/aurora4/a00/steps/pretrain_dnn.sh:120-133),
+    written by the reference's nnet-copy in text and in binary."""
+    rs = np.random.RandomState(9091)
+    D, ctx = 6, 5
+    offsets = list(range(-ctx, ctx + 1))
+    spliced = D * len(offsets)                       # 66
+    pick = rs.permutation(spliced)[:40]              # 0-based column indices kept by <copy>
+    bl = O.BiasedLinearity((0.3 * rs.randn(24, 40)).astype(f32), (-0.5 + 0.2 * rs.rand(24)).astype(f32))
+    transf = [O.Expand(D, spliced, offsets), O.Copy(spliced, 40, pick), bl, O.Sigmoid(24)]
+    net = make_dnn(rs, [24, 32, 17])
+    lengths = [30, 3, 41, 1, 12, 25, 37]             # utterances shorter than the context included
+    utts = [("fx%02d" % i, rs.randn(n, D).astype(f32)) for i, n in enumerate(lengths)]
+    alis = [(k, rs.randint(0, 17, m.shape[0]).astype(np.int32)) for k, m in utts]
+    P = lambda n: os.path.join(tmp, n)
+    open(P("t.txt"), "wb").write(O.write_nnet(transf, False))
+    open(P("n.bin"), "wb").write(O.write_nnet(net, True))
+    open(P("xf.ark"), "wb").write(O.write_matrix_ark(utts))
+    open(P("xa.ark"), "wb").write(O.write_int32_vector_ark(alis, binary=False))
+    fix = {"transf_txt_in": np.frombuffer(O.write_nnet(transf, False), np.uint8),
+           "model": np.frombuffer(O.write_nnet(net, True), np.uint8),
+           "feats_ark": np.frombuffer(O.write_matrix_ark(utts), np.uint8),
+           "ali_ark_txt": np.frombuffer(O.write_int32_vector_ark(alis, binary=False), np.uint8),
+           "offsets": np.array(offsets), "pick0": np.array(pick)}
+    # the transform as the reference re-writes it, both formats, both directions
+    run([os.path.join(BIN, "nnet-copy"), "--binary=true", P("t.txt"), P("t.bin")])
+    run([os.path.join(BIN, "nnet-copy"), "--binary=false", P("t.bin"), P("t2.txt")])
+    fix["transf_bin"] = np.frombuffer(open(P("t.bin"), "rb").read(), np.uint8)
+    fix["transf_txt"] = np.frombuffer(open(P("t2.txt"), "rb").read(), np.uint8)
+    # the transform alone and transform + network through nnet-forward
+    _, err = run([os.path.join(BIN, "nnet-forward"), P("t.bin"), "ark:" + P("xf.ark"), "ark:" + P("xt.ark")])
+    for k, m in O.read_matrix_ark(open(P("xt.ark"), "rb").read()):
+        fix["transformed_" + k] = m
+    for name, tf in (("bin", "t.bin"), ("txt", "t2.txt")):
+        run([os.path.join(BIN, "nnet-forward"), "--feature-transform=" + P(tf), P("n.bin"), "ark:" + P("xf.ark"), "ark:" + P("xo.ark")])
+        for k, m in O.read_matrix_ark(open(P("xo.ark"), "rb").read()):
+            fix["post_%s_%s" % (name, k)] = m
+    # training with the transform in front
+    for name, opts in {"train": ["--randomize=false"], "train_rand": [], "cv": ["--cross-validate=true"]}.items():
+        args = [os.path.join(BIN, "nnet-train-xent-hardlab-frmshuff"), "--bunchsize=16", "--cachesize=64", "--binary=true",
+                "--feature-transform=" + P("t.bin")] + opts + ["ark:" + P("xf.ark"), "ark:" + P("xa.ark"), P("n.bin")]
+        if name != "cv":
+            args.append(P("no.nnet"))
+        _, err = run(args)
+        m = re.search(r"Xent:(\S+) frames:(\d+) err/frm:(\S+)\s*\nFRAME_ACCURACY >> (\S+)% <<", err)
+        fix[name + "_xent"], fix[name + "_frames"], fix[name + "_acc"] = np.float64(m.group(1)), np.int64(m.group(2)), np.float64(m.group(4))
+        fix[name + "_report"] = np.frombuffer(m.group(0).encode(), np.uint8)
+        if name != "cv":
+            fix[name + "_model_out"] = np.frombuffer(open(P("no.nnet"), "rb").read(), np.uint8)
+    # RBM pre-training on the transformed features (Bernoulli visible = the transform's sigmoid outputs, Gaussian
+    # hidden: the only hidden type the reference's CPU path can run).  Its noise comes from rand(), this
+    # repository's from the device generator, so only the frame count of its report can be pinned.
+    rbm = O.Rbm((0.1 * rs.randn(20, 24)).astype(f32), np.zeros(24, f32), np.zeros(20, f32), "bern", "gauss")
+    open(P("r.rbm"), "wb").write(O.write_nnet([rbm], True))
+    fix["rbm"] = np.frombuffer(O.write_nnet([rbm], True), np.uint8)
+    _, err = run([os.path.join(BIN, "rbm-train-cd1-frmshuff"), "--bunchsize=16", "--cachesize=64", "--binary=true",
+                  "--learn-rate=0.001", "--feature-transform=" + P("t.bin"), P("r.rbm"), "ark:" + P("xf.ark"), P("ro.rbm")])
+    m = re.search(r"Mse:(\S+) frames:(\d+) err/frm:(\S+)", err)
+    fix["rbm_frames"], fix["rbm_mse_per_frame_reference"] = np.int64(m.group(2)), np.float64(m.group(3))
+    np.savez_compressed(os.path.join(HERE, "transform_small.npz"), **fix)
+    print("transform_small: %d arrays" % len(fix))
+
+
+GENERATORS = {"dnn_steps": gen_dnn_steps, "forward": gen_forward, "train_e2e": gen_train_e2e, "rbm": gen_rbm,
+              "rm_shape": gen_rm_shape, "siblings": gen_siblings, "transform": gen_transform}
+
 if __name__ == "__main__":
     if not os.path.exists(os.path.join(BIN, "ref_dump")):
         sys.exit("build the reference first: make -C oracle ref")
+    which = sys.argv[1:] or list(GENERATORS)      # python tests/golden/make_golden.py [name ...]
     with tempfile.TemporaryDirectory() as tmp:
-        gen_dnn_steps(tmp)
-        gen_forward(tmp)
-        gen_train_e2e(tmp)
-        gen_rbm(tmp)
-        gen_rm_shape(tmp)
-        gen_siblings(tmp)
+        for name in which:
+            GENERATORS[name](tmp)

@@ -7,6 +7,7 @@
     the union of their outputs equals the single-process output bit for bit.
 """
 import os
+import re
 import subprocess
 
 import numpy as np
@@ -87,20 +88,33 @@ def test_forward_sharded_over_two_ranks_equals_single(hip, nn, tmp_path):
     base = [exe, "--silent=true", str(tmp_path / "m.nnet"), "ark:" + str(tmp_path / "f.ark")]
     r = subprocess.run(base + ["ark:" + str(tmp_path / "single.ark")], stderr=subprocess.PIPE, timeout=110)
     assert r.returncode == 0, r.stderr.decode()[-2000:]
-    procs = [subprocess.Popen([exe, "--silent=true", "--num-ranks=2", "--rank=%d" % k, "--gpu-id=0",
-                               str(tmp_path / "m.nnet"), "ark:" + str(tmp_path / "f.ark"),
-                               "ark:" + str(tmp_path / "shard.JOB.ark")], stderr=subprocess.PIPE) for k in range(2)]
-    for p in procs:
-        _, err = p.communicate(timeout=110)
-        assert p.returncode == 0, err.decode()[-2000:]
     single = dict(O.read_matrix_ark((tmp_path / "single.ark").read_bytes()))
-    shards = [dict(O.read_matrix_ark((tmp_path / ("shard.%d.ark" % (k + 1))).read_bytes())) for k in range(2)]
-    assert not set(shards[0]) & set(shards[1])
-    assert set(shards[0]) | set(shards[1]) == set(single)
     want = nn.shard_assign(2, lens)
-    for i, (k, _) in enumerate(utts):
-        assert k in shards[want[i]]                                    # the documented rule
-        np.testing.assert_array_equal(shards[want[i]][k], single[k])   # same kernels, same rows: bit for bit
+    # the same table as a script file: "key archive:offset" (offset of the entry's value)
+    ark = (tmp_path / "f.ark").read_bytes()
+    pos, lines = 0, []
+    for k, m in utts:
+        pos = ark.index(k.encode() + b" \0B", pos) + len(k) + 1
+        lines.append("%s %s:%d\n" % (k, tmp_path / "f.ark", pos))
+    (tmp_path / "f.scp").write_text("".join(lines))
+    payload = [n * dims[0] * 4 for n in lens]
+    for rspec in ("ark:" + str(tmp_path / "f.ark"), "scp:" + str(tmp_path / "f.scp")):
+        procs = [subprocess.Popen([exe, "--num-ranks=2", "--rank=%d" % k, "--gpu-id=0", str(tmp_path / "m.nnet"), rspec,
+                                   "ark:" + str(tmp_path / "shard.JOB.ark")], stderr=subprocess.PIPE) for k in range(2)]
+        read = []
+        for p in procs:
+            _, err = p.communicate(timeout=110)
+            assert p.returncode == 0, err.decode()[-2000:]
+            read.append(int(re.search(r"feature payload read (\d+) bytes", err.decode()).group(1)))
+        shards = [dict(O.read_matrix_ark((tmp_path / ("shard.%d.ark" % (k + 1))).read_bytes())) for k in range(2)]
+        assert not set(shards[0]) & set(shards[1])
+        assert set(shards[0]) | set(shards[1]) == set(single)
+        for i, (k, _) in enumerate(utts):
+            assert k in shards[want[i]]                                    # the documented rule
+            np.testing.assert_array_equal(shards[want[i]][k], single[k])   # same kernels, same rows: bit for bit
+        # a rank reads the payload of its own utterances only (the others are skipped on their header)
+        for k in range(2):
+            assert read[k] == sum(b for b, w in zip(payload, want) if w == k), (rspec, read, payload, list(want))
 
 
 @pytest.mark.parametrize("mode", ["alone", "torch"])
@@ -114,3 +128,45 @@ def test_rccl_communicator_single_rank(hip, mode):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29547")
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=110, env=env)
     assert r.returncode == 0 and b"rccl probe ok" in r.stdout, r.stderr.decode()[-2000:]
+
+
+def test_dp_tool_loop_uneven_shards_and_report_contract(hip, nn, tmp_path):
+    """The multi-rank loop of nnet-train-xent-hardlab-frmshuff, each rank of 2 run on its own with the stand-in
+    communicator (KALDI_AMD_COMM_LOOPBACK: sums x2, min / max local): a table on which rank 1's shard runs dry
+    before its cache holds one bunch (it must neither abort in Cache::Randomize nor leave the collectives), every
+    rank reads only its own payload, and the log keeps the recipes' contract (train_scheduler.sh:85,109,120:
+    awk '/FRAME_ACCURACY/{acc=$3}' keeps the LAST match): rank 0 prints the all-rank report as its only
+    FRAME_ACCURACY line, in Xent::Report()'s format; the other rank prints none."""
+    rs = np.random.RandomState(9)
+    dims = [20, 32, 9]
+    data, _ = _model_bytes(rs, dims)
+    (tmp_path / "m.nnet").write_bytes(data)
+    lens = [300, 20]                   # rank 0 gets 300 frames, rank 1 20: less than one bunch of 64
+    utts = [("u%02d" % i, rs.standard_normal((n, dims[0])).astype(f32)) for i, n in enumerate(lens)]
+    alis = [(k, rs.randint(0, dims[-1], m.shape[0]).astype(np.int32)) for k, m in utts]
+    (tmp_path / "f.ark").write_bytes(O.write_matrix_ark(utts))
+    (tmp_path / "a.ark").write_bytes(O.write_int32_vector_ark(alis))
+    want = nn.shard_assign(2, lens)
+    assert list(want) == [0, 1]
+    exe = os.path.join(nn.BIN_DIR, "nnet-train-xent-hardlab-frmshuff")
+    env = dict(os.environ, KALDI_AMD_COMM_LOOPBACK="1")
+    logs = []
+    for rank in range(2):
+        r = subprocess.run([exe, "--num-ranks=2", "--rank=%d" % rank, "--gpu-id=0", "--bunchsize=64", "--cachesize=512",
+                            "--learn-rate=0.01", "ark:" + str(tmp_path / "f.ark"), "ark:" + str(tmp_path / "a.ark"),
+                            str(tmp_path / "m.nnet"), str(tmp_path / ("out%d.nnet" % rank))],
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=110, env=env)
+        assert r.returncode == 0, r.stderr.decode()[-3000:]
+        logs.append(r.stderr.decode())
+        (tmp_path / ("log%d" % rank)).write_text(logs[-1])
+        read = int(re.search(r"feature payload read (\d+) bytes", logs[-1]).group(1))
+        assert read == sum(n * dims[0] * 4 for n, w in zip(lens, want) if w == rank)
+    # rank 0: 300 frames -> 4 whole bunches of 64; the stand-in communicator doubles the sums
+    m = re.search(r"Xent:(\S+) frames:(\d+) err/frm:(\S+)\nFRAME_ACCURACY >> (\S+)% <<", logs[0])
+    assert m and int(m.group(2)) == 2 * 256, logs[0][-1500:]
+    assert logs[0].count("FRAME_ACCURACY") == 1 and "FRAME_ACCURACY" not in logs[1]
+    assert "shard frames:0 " in logs[1]                      # rank 1 trained nothing and still finished cleanly
+    awk = subprocess.run(["awk", '/FRAME_ACCURACY/{ acc=$3; sub(/%/,"",acc); } END{print acc}', str(tmp_path / "log0")],
+                         stdout=subprocess.PIPE).stdout.decode().strip()
+    assert abs(float(awk) - float(m.group(4))) < 1e-6
+    assert (tmp_path / "out0.nnet").exists() and not (tmp_path / "out1.nnet").exists()   # rank 0 writes the model

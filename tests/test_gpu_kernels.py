@@ -479,7 +479,7 @@ def test_affine_forward_backward_update(hip, N, O_, I):
 @pytest.mark.parametrize("mom", [0.0, 0.9])
 def test_affine_update_fused_equals_halves(hip, N, O_, I, mom):
     """hipF_affine_update_fused (weight pass + bias pass in one launch, the bias sums taken by extra workgroups at
-    the end of the gradient GEMM's grid) against hipF_affine_update_weights + hipF_affine_update_bias: same bits,
+    the start of the gradient GEMM's grid) against hipF_affine_update_weights + hipF_affine_update_bias: same bits,
     into a second weight buffer and in place, outputs that are no multiple of the tile (ragged last bias tile)."""
     h = hip
     x, e = rnd((N, I), 70), rnd((N, O_), 71, 0.01)

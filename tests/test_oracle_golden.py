@@ -134,6 +134,50 @@ def run_trainer(g, opts, randomize):
     return net, xent, cache_lines
 
 
+def _transform(g):
+    return O.Nnet(O.read_nnet(g["transf_bin"].tobytes()))
+
+
+def test_feature_transform_matches_reference():
+    """<expand> / <copy> components and --feature-transform (nnet/nnet-various.h:35-135, nnetbin/nnet-forward.cc:66-75,
+    127-131): the oracle against the reference's nnet-copy (both file formats, byte for byte: offsets stored as a
+    double vector, <copy> indices 1-based on disk), its nnet-forward on the transform alone and in front of a
+    network, and its trainer with the transform in front."""
+    g = load("transform_small.npz")
+    for enc in ("transf_bin", "transf_txt"):
+        layers = O.read_nnet(g[enc].tobytes())
+        assert [type(l).__name__ for l in layers] == ["Expand", "Copy", "BiasedLinearity", "Sigmoid"]
+        assert layers[0].offsets == list(g["offsets"]) and layers[1].indices == list(g["pick0"])
+        assert O.write_nnet(layers, True) == g["transf_bin"].tobytes()
+        assert O.write_nnet(layers, False) == g["transf_txt"].tobytes()
+    transf, net = _transform(g), O.Nnet(O.read_nnet(g["model"].tobytes()))
+    for key, mat in O.read_matrix_ark(g["feats_ark"].tobytes()):
+        t = transf.propagate(mat)
+        close(t, g["transformed_" + key])
+        for enc in ("bin", "txt"):
+            np.testing.assert_allclose(net.propagate(t), g["post_%s_%s" % (enc, key)], rtol=1e-4, atol=1e-9)
+
+
+@pytest.mark.parametrize("name,opts,randomize", [("train", dict(learn_rate=0.008), False),
+                                                 ("train_rand", dict(learn_rate=0.008), True),
+                                                 ("cv", dict(learn_rate=0.0), False)])
+def test_trainer_with_feature_transform_matches_reference(name, opts, randomize):
+    g = dict(load("transform_small.npz"))
+    transf = _transform(g)
+    # the trainer sees the transformed utterances (nnet-train-xent-hardlab-frmshuff.cc:148)
+    g["feats_ark"] = np.frombuffer(O.write_matrix_ark([(k, transf.propagate(m)) for k, m in
+                                                       O.read_matrix_ark(g["feats_ark"].tobytes())]), np.uint8)
+    net, xent, _ = run_trainer(g, opts, randomize)
+    assert xent.frames == int(g[name + "_frames"])
+    assert abs(xent.loss - float(g[name + "_xent"])) <= 2e-5 * abs(xent.loss)
+    assert abs(100.0 * xent.correct / xent.frames - float(g[name + "_acc"])) < 1e-3
+    if name != "cv":
+        for a, b in zip(net.layers, O.read_nnet(g[name + "_model_out"].tobytes())):
+            if isinstance(a, O.BiasedLinearity):
+                close(a.W, b.W, rtol=5e-5, atol=5e-6)
+                close(a.b, b.b, rtol=5e-5, atol=5e-6)
+
+
 @pytest.mark.parametrize("name,opts,randomize", [
     ("norand", dict(learn_rate=0.008), False),
     ("rand", dict(learn_rate=0.008), True),
