@@ -398,7 +398,56 @@ def gen_transform(tmp):
     print("transform_small: %d arrays" % len(fix))
 
 
-GENERATORS = {"dnn_steps": gen_dnn_steps, "forward": gen_forward, "train_e2e": gen_train_e2e, "rbm": gen_rbm,
+def rm_shape_net(seed):
+    """the RM-sized model, bunch and labels of gen_rm_shape / gen_rm_multistep, regenerated from the seed by the tests"""
+    rs = np.random.RandomState(seed)
+    dims = [440, 1024, 1024, 1024, 1024, 1483]
+    N = 256
+    layers = []
+    for i in range(len(dims) - 1):
+        W = (0.1 * rs.randn(dims[i + 1], dims[i])).astype(f32)
+        last = i == len(dims) - 2
+        b = np.zeros(dims[i + 1], f32) if last else (-4.1 + 0.2 * rs.rand(dims[i + 1])).astype(f32)
+        layers.append(O.BiasedLinearity(W, b))
+        layers.append(O.Softmax(dims[i + 1]) if last else O.Sigmoid(dims[i + 1]))
+    x = rs.randn(N, dims[0]).astype(f32)
+    tgt = rs.randint(0, dims[-1], N).astype(np.int32)
+    return dims, N, layers, x, tgt
+
+
+def gen_rm_multistep(tmp):
+    """Three consecutive training steps at the RM size (bunch 256), momentum 0 and 0.9 (a learning rate large enough
+    for the steps to differ visibly): per-step summaries of the posteriors and the running loss / accuracy, and
+    samples of every layer's weights and biases after the last step.  Pins the oracle at this size over more than one
+    step: the next forward pass must see the weights the previous step wrote."""
+    dims, N, layers, x, tgt = rm_shape_net(2025)
+    open(os.path.join(tmp, "rmm.bin"), "wb").write(O.write_nnet(layers, True))
+    open(os.path.join(tmp, "rmmf.ark"), "wb").write(O.write_matrix_ark([("u", x)]))
+    open(os.path.join(tmp, "rmma.ark"), "wb").write(O.write_int32_vector_ark([("u", tgt)]))
+    fix = {"seed": np.int64(2025), "dims": np.array(dims), "N": np.int64(N), "nsteps": np.int64(3), "lr": np.float64(0.05)}
+    for name, mom in (("mom0", "0.0"), ("mom9", "0.9")):
+        oark = os.path.join(tmp, "rmmo.ark")
+        run([os.path.join(BIN, "ref_dump"), "dnn", os.path.join(tmp, "rmm.bin"), os.path.join(tmp, "rmmf.ark"),
+             os.path.join(tmp, "rmma.ark"), oark, "3", "0.05", mom, "0.0", "0.0", "0.0", "0"])
+        d = archive_to_dict(open(oark, "rb").read())
+        for s in range(3):
+            post = d["s%d_post" % s]
+            fix["%s_s%d_post_cols" % (name, s)] = post[:, :16].copy()
+            fix["%s_s%d_post_tgt" % (name, s)] = post[np.arange(N), tgt].copy()
+            fix["%s_s%d_post_argmax" % (name, s)] = post.argmax(1).astype(np.int32)
+            fix["%s_s%d_cumloss" % (name, s)] = np.float64(scalar(d["s%d_cumloss" % s]))
+            fix["%s_s%d_cumacc" % (name, s)] = np.float64(scalar(d["s%d_cumacc" % s]))
+        for i in range(0, 2 * (len(dims) - 1), 2):
+            W = d["s2_W%d" % i]
+            fix["%s_W%d_rows" % (name, i)] = W[:4].copy()
+            fix["%s_W%d_diag" % (name, i)] = np.array([W[j % W.shape[0], (7 * j) % W.shape[1]] for j in range(512)])
+            fix["%s_W%d_abs_sum" % (name, i)] = np.float64(np.abs(W.astype(np.float64)).sum())
+            fix["%s_b%d" % (name, i)] = d["s2_b%d" % i][0].copy()
+    np.savez_compressed(os.path.join(HERE, "rm_shape_multistep.npz"), **fix)
+    print("rm_shape_multistep: %d arrays" % len(fix))
+
+
+GENERATORS = {"rm_multistep": gen_rm_multistep, "dnn_steps": gen_dnn_steps, "forward": gen_forward, "train_e2e": gen_train_e2e, "rbm": gen_rbm,
               "rm_shape": gen_rm_shape, "siblings": gen_siblings, "transform": gen_transform}
 
 if __name__ == "__main__":

@@ -170,3 +170,43 @@ def test_dp_tool_loop_uneven_shards_and_report_contract(hip, nn, tmp_path):
                          stdout=subprocess.PIPE).stdout.decode().strip()
     assert abs(float(awk) - float(m.group(4))) < 1e-6
     assert (tmp_path / "out0.nnet").exists() and not (tmp_path / "out1.nnet").exists()   # rank 0 writes the model
+
+
+@pytest.mark.parametrize("exchange", ["sum", "gather"])
+def test_data_parallel_three_steps_rm_shape_equal_oracle_on_stacked_bunch(hip, nn, tmp_path, monkeypatch, exchange):
+    """The three-stream data-parallel step (gradient GEMMs, exchange and shared step beside the back-propagation) over
+    three consecutive steps at the RM size, kernels long enough to overlap: two stand-in ranks on a bunch equal the
+    numpy oracle on that bunch stacked twice -- weights and biases of every layer, momentum 0.9."""
+    rs = np.random.RandomState(2025)
+    dims, N, R, lr, mom = [440, 1024, 1024, 1024, 1024, 1483], 256, 2, 0.02, 0.9
+    layers = []
+    for i in range(len(dims) - 1):
+        last = i == len(dims) - 2
+        layers.append(O.BiasedLinearity((0.1 * rs.randn(dims[i + 1], dims[i])).astype(f32),
+                                        np.zeros(dims[i + 1], f32) if last else (-4.1 + 0.2 * rs.rand(dims[i + 1])).astype(f32)))
+        layers.append(O.Softmax(dims[i + 1]) if last else O.Sigmoid(dims[i + 1]))
+    model = tmp_path / "m.nnet"
+    model.write_bytes(O.write_nnet(layers, True))
+    X = rs.randn(3, N, dims[0]).astype(f32)
+    T = rs.randint(0, dims[-1], (3, N)).astype(np.int32)
+    net = O.Nnet(layers)
+    net.set_train_opts(lr, momentum=mom, average_grad=True)
+    xent = O.Xent()
+    hip.call("hipK_comm_init_loopback", R)
+    try:
+        dp = nn.Trainer(str(model))
+        dp.set_train_opts(lr, mom, 0.0, 0.0, 0.0, True, True)
+        monkeypatch.setenv("KALDI_AMD_DP_EXCHANGE", exchange)
+        dp.set_data_parallel(R)
+        for s in range(3):
+            x, t = hip.DevMatrix.from_numpy(X[s]), hip.DevMatrix.from_numpy(T[s], pitched=False)
+            dp.train_bunch(x.ptr, x.stride, N, dims[0], t.ptr)
+            diff, _, _, _ = xent.eval_vec(net.propagate(np.concatenate([X[s]] * R)), np.concatenate([T[s]] * R))
+            net.backpropagate(diff)
+        for i in range(0, 2 * (len(dims) - 1), 2):
+            W, b = dp.layer_params(i, dims[i // 2 + 1], dims[i // 2])
+            np.testing.assert_allclose(W, net.layers[i].W, rtol=2e-4, atol=2e-6 * np.abs(net.layers[i].W).max())
+            np.testing.assert_allclose(b, net.layers[i].b, rtol=2e-4, atol=2e-6 * max(np.abs(net.layers[i].b).max(), 1e-3))
+        dp.close()
+    finally:
+        hip.call("hipK_comm_destroy")

@@ -117,6 +117,75 @@ def test_gradients_match_reference_rm_shape(hip, nn, tmp_path):
     t.close()
 
 
+def _sigmoid_dnn(seed, dims, N):
+    rs = np.random.RandomState(seed)
+    layers = []
+    for i in range(len(dims) - 1):
+        W = (0.1 * rs.randn(dims[i + 1], dims[i])).astype(f32)
+        last = i == len(dims) - 2
+        b = np.zeros(dims[i + 1], f32) if last else (-4.1 + 0.2 * rs.rand(dims[i + 1])).astype(f32)
+        layers.append(O.BiasedLinearity(W, b))
+        layers.append(O.Softmax(dims[i + 1]) if last else O.Sigmoid(dims[i + 1]))
+    return layers, rs.randn(N, dims[0]).astype(f32), rs.randint(0, dims[-1], N).astype(np.int32)
+
+
+def _steps_against_oracle(hip, nn, tmp_path, layers, dims, bunches, lr, mom, fixture=None, name=None):
+    """Consecutive fused training steps on the GPU against oracle.Nnet on the same bunches (and, step by step,
+    against a reference fixture where there is one): posteriors 1e-4, running loss 1e-3, correct counts exactly,
+    and after the last step the weights and biases of EVERY layer.  A step that read stale weights, or an update
+    that raced with the next forward pass, shows up here."""
+    model = tmp_path / "m.nnet"
+    model.write_bytes(O.write_nnet(layers, True))
+    net = O.Nnet(layers)
+    net.set_train_opts(lr, momentum=mom)
+    xent = O.Xent()
+    t = nn.Trainer(str(model))
+    t.set_train_opts(lr, mom)
+    for s, (x, tgt) in enumerate(bunches):
+        N = x.shape[0]
+        dx, dt = hip.DevMatrix.from_numpy(x), hip.DevMatrix.from_numpy(tgt, pitched=False)
+        t.train_bunch(dx.ptr, dx.stride, N, dims[0], dt.ptr)
+        post = t.posteriors(N)
+        ref = net.propagate(x)
+        diff, _, _, _ = xent.eval_vec(ref, tgt)
+        net.backpropagate(diff)
+        np.testing.assert_allclose(post, ref, rtol=1e-4, atol=1e-10)                                  # posteriors 1e-4
+        frames, correct, loss = t.stats()
+        assert frames == xent.frames and correct == xent.correct                                     # counts exactly
+        assert abs(loss - xent.loss) <= 1e-3 * abs(xent.loss)                                        # loss 1e-3
+        if fixture is not None:
+            np.testing.assert_allclose(post[:, :16], fixture["%s_s%d_post_cols" % (name, s)], rtol=1e-4, atol=1e-12)
+            assert (post.argmax(1) == fixture["%s_s%d_post_argmax" % (name, s)]).all()
+            assert abs(loss - float(fixture["%s_s%d_cumloss" % (name, s)])) <= 1e-3 * abs(loss)
+            assert abs(100.0 * correct / frames - float(fixture["%s_s%d_cumacc" % (name, s)])) < 1e-3
+    for i in range(0, 2 * (len(dims) - 1), 2):
+        W, b = t.layer_params(i, dims[i // 2 + 1], dims[i // 2])
+        close_scaled(W, net.layers[i].W, 2e-5)
+        close_scaled(b, net.layers[i].b, 2e-5)
+        if fixture is not None:
+            np.testing.assert_allclose(W[:4], fixture["%s_W%d_rows" % (name, i)], rtol=1e-4, atol=1e-6)
+            np.testing.assert_allclose(b, fixture["%s_b%d" % (name, i)], rtol=1e-4, atol=1e-6)
+    t.close()
+
+
+@pytest.mark.parametrize("name,mom", [("mom0", 0.0), ("mom9", 0.9)])
+def test_three_steps_rm_shape_match_reference_and_oracle(hip, nn, tmp_path, name, mom):
+    g = load("rm_shape_multistep.npz")
+    dims, N = [int(d) for d in g["dims"]], int(g["N"])
+    layers, x, tgt = _sigmoid_dnn(int(g["seed"]), dims, N)
+    _steps_against_oracle(hip, nn, tmp_path, layers, dims, [(x, tgt)] * int(g["nsteps"]), float(g["lr"]), mom, g, name)
+
+
+def test_two_steps_swbd_shape_match_oracle(hip, nn, tmp_path):
+    """the whole Switchboard-sized network (1320 -> 7 x 2048 -> 9000, bunch 256), two steps on different bunches,
+    against the numpy oracle (pinned at the RM size by the reference fixtures)"""
+    dims, N = [1320] + [2048] * 7 + [9000], 256
+    layers, x, tgt = _sigmoid_dnn(31, dims, N)
+    rs = np.random.RandomState(32)
+    x2, tgt2 = rs.randn(N, dims[0]).astype(f32), rs.randint(0, dims[-1], N).astype(np.int32)
+    _steps_against_oracle(hip, nn, tmp_path, layers, dims, [(x, tgt), (x2, tgt2)], 0.008, 0.0)
+
+
 def test_forward_tool_matches_reference(hip, nn, tmp_path):
     g = load("forward_small.npz")
     (tmp_path / "m.nnet").write_bytes(g["model"].tobytes())

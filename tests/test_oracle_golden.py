@@ -361,3 +361,44 @@ def test_libc_rand_helpers():
     # glibc's first value for the default seed is 1804289383
     O.srand(1)
     assert O._rand() == 1804289383
+
+
+def _rm_net(seed):
+    rs = np.random.RandomState(seed)
+    dims = [440, 1024, 1024, 1024, 1024, 1483]
+    N = 256
+    layers = []
+    for i in range(len(dims) - 1):
+        W = (0.1 * rs.randn(dims[i + 1], dims[i])).astype(f32)
+        last = i == len(dims) - 2
+        b = np.zeros(dims[i + 1], f32) if last else (-4.1 + 0.2 * rs.rand(dims[i + 1])).astype(f32)
+        layers.append(O.BiasedLinearity(W, b))
+        layers.append(O.Softmax(dims[i + 1]) if last else O.Sigmoid(dims[i + 1]))
+    return dims, N, layers, rs.randn(N, dims[0]).astype(f32), rs.randint(0, dims[-1], N).astype(np.int32)
+
+
+@pytest.mark.parametrize("name,mom", [("mom0", 0.0), ("mom9", 0.9)])
+def test_rm_shape_multistep_matches_reference(name, mom):
+    """three consecutive steps at the RM size against the reference's (ref_dump): the oracle stays pinned at this
+    size when one step's updated weights feed the next step's forward pass"""
+    g = load("rm_shape_multistep.npz")
+    dims, N, layers, x, tgt = _rm_net(int(g["seed"]))
+    net = O.Nnet(layers)
+    net.set_train_opts(float(g["lr"]), momentum=mom)
+    xent = O.Xent()
+    for s in range(int(g["nsteps"])):
+        post = net.propagate(x)
+        np.testing.assert_allclose(post[:, :16], g["%s_s%d_post_cols" % (name, s)], rtol=1e-4, atol=1e-12)
+        np.testing.assert_allclose(post[np.arange(N), tgt], g["%s_s%d_post_tgt" % (name, s)], rtol=1e-4, atol=1e-12)
+        assert (post.argmax(1) == g["%s_s%d_post_argmax" % (name, s)]).all()
+        diff, _, _, _ = xent.eval_vec(post, tgt)
+        assert abs(xent.loss - float(g["%s_s%d_cumloss" % (name, s)])) <= 1e-4 * abs(xent.loss)
+        assert abs(100.0 * xent.correct / xent.frames - float(g["%s_s%d_cumacc" % (name, s)])) < 1e-3
+        net.backpropagate(diff)
+    for i in range(0, 2 * (len(dims) - 1), 2):
+        W = net.layers[i].W
+        close(W[:4], g["%s_W%d_rows" % (name, i)], rtol=1e-4, atol=1e-6)
+        close(np.array([W[j % W.shape[0], (7 * j) % W.shape[1]] for j in range(512)]), g["%s_W%d_diag" % (name, i)],
+              rtol=1e-4, atol=1e-6)
+        assert abs(np.abs(W.astype(np.float64)).sum() - float(g["%s_W%d_abs_sum" % (name, i)])) < 1e-4 * float(g["%s_W%d_abs_sum" % (name, i)])
+        close(net.layers[i].b, g["%s_b%d" % (name, i)], rtol=1e-4, atol=1e-6)
