@@ -233,6 +233,19 @@ unsigned long long *g_stamps = nullptr;
 constexpr size_t kStampSlots = 16 * 65536;
 #endif
 
+// The update epilogue's 16-byte form needs W, Wout (and the momentum buffer) 16-byte aligned with leading
+// dimensions and N multiples of 4, each below 2 GiB (buffer addressing); otherwise it stays element-wise.
+void set_update_footprints(GemmParams &p) {
+  static const bool off = getenv("KALDI_HIP_UPDATE_SCALAR_EPILOGUE") != nullptr;  // for A/B measurements
+  auto bytes = [&](int ld) { return ((double)(p.M - 1) * ld + p.N) * 4.0; };
+  const bool ok = !off && p.N % 4 == 0 && p.ldw % 4 == 0 && p.ldwout % 4 == 0 && kh::aligned16(p.W) && kh::aligned16(p.Wout) &&
+                  (!p.C || (p.ldc % 4 == 0 && kh::aligned16(p.C))) && bytes(p.ldw) < 2147483648.0 &&
+                  bytes(p.ldwout) < 2147483648.0 && (!p.C || bytes(p.ldc) < 2147483648.0);
+  p.w_bytes = ok ? (int)bytes(p.ldw) : 0;
+  p.wout_bytes = ok ? (int)bytes(p.ldwout) : 0;
+  p.c_bytes = (ok && p.C) ? (int)bytes(p.ldc) : 0;
+}
+
 GemmParams base_params(int M, int N, int K, const float *A, int lda, const float *B, int ldb, float *C, int ldc) {
   GemmParams p;
   memset(&p, 0, sizeof(p));
@@ -551,11 +564,7 @@ KH_EXPORT int hipF_affine_update_weights(khStream_t s, int32_t N, int32_t O, int
   p.ldw = ldw_in;
   p.Wout = W_out;
   p.ldwout = ldw_out;
-  {
-    // experiments: fewer update workgroups per compute unit leave room for the kernels of the main stream
-    static const int pad = getenv("KALDI_HIP_UPDATE_LDS_PAD") ? atoi(getenv("KALDI_HIP_UPDATE_LDS_PAD")) : 0;
-    p.dyn_lds = pad;
-  }
+  set_update_footprints(p);
   return run_gemm<EPI_UPDATE>(s, false, false, p, /*allow_split=*/false);
 }
 
@@ -577,6 +586,7 @@ KH_EXPORT int hipF_affine_update_fused(khStream_t s, int32_t N, int32_t O, int32
   p.ldw = ldw_in;
   p.Wout = W_out;
   p.ldwout = ldw_out;
+  set_update_footprints(p);
   p.bias_io = bias;
   p.bcorr = bcorr;
   p.bias_tiles = (O + 63) / 64;  // ride at the start of the GEMM's grid

@@ -46,6 +46,9 @@ struct GemmParams {
   float lr, l2, mom;
   int act;
   int dyn_lds;     // extra LDS bytes to request at launch (caps how many workgroups share a compute unit)
+  // EPI_UPDATE: footprints of W / Wout / C (< 2 GiB) when the epilogue may use 16-byte buffer accesses on them
+  // (all 16-byte aligned, leading dimensions and N multiples of 4), else 0: see the epilogue
+  int w_bytes, wout_bytes, c_bytes;
   // EPI_UPDATE only: the bias half of the update, done by `bias_tiles` extra workgroups at the start of the grid
   // (bias_io -= lr * (alpha * colsum(A) + mom * bcorr); A is the error matrix, K x M as stored)
   float *bias_io;
@@ -407,7 +410,25 @@ __device__ __forceinline__ void gemm_tile(const GemmParams &p, float *lds, const
   float pre[NPRE][16];
   const bool full_tile = (m0 + BM <= p.M) && (n0 + BN <= p.N);
   int npre = 0;  // accumulators whose operand is in `pre`
+  // Two layouts of one accumulator's worth of old weights in `pre`.  Plain: register r = the element of accumulator
+  // register r (16 four-byte loads).  Vector (p.w_bytes != 0): registers 4*pass .. 4*pass+3 = four consecutive
+  // columns of row (lane / 8 + 8 * pass) of the 32 x 32 block, one 16-byte buffer load each; rows past the matrix
+  // read 0 (buffer bounds), so edge tiles take this form too.
+  const bool epi_vec = PREFETCH && p.w_bytes != 0;
+  const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc((void *)p.W, 0, p.w_bytes, 0x00020000);
+  auto vec_off = [&](int a, int pass, int ld) {  // byte offset of this lane's 4 columns of row `pass` of accumulator a
+    const int i = a / TN, q = a % TN;
+    return ((m0 + wm0 + i * 32 + (lane >> 3) + 8 * pass) * ld + (n0 + wn0 + q * 32 + (lane & 7) * 4)) * 4;
+  };
   auto prefetch_acc = [&](int a) {
+    if (epi_vec) {
+#pragma unroll
+      for (int pass = 0; pass < 4; ++pass) {
+        const float4 t = buf_load(rsrc_w, vec_off(a, pass, p.ldw), 0);
+        pre[a][4 * pass] = t.x; pre[a][4 * pass + 1] = t.y; pre[a][4 * pass + 2] = t.z; pre[a][4 * pass + 3] = t.w;
+      }
+      return;
+    }
     const int i = a / TN, q = a % TN;
     const float *src = p.W + (size_t)(m0 + wm0 + i * 32 + 4 * lh) * p.ldw + (n0 + wn0 + q * 32 + li);
 #pragma unroll
@@ -507,7 +528,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams &p, float *lds, const
       }
     };
     auto steady = [&](auto par_tag) {
-      if (PREFETCH && full_tile) {
+      if (PREFETCH && (full_tile || epi_vec)) {
 #pragma unroll
         for (int a = 0; a < NPRE; ++a)
           if (kt == a) {
@@ -598,7 +619,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams &p, float *lds, const
       }
     };
     auto steady = [&]() {
-      if (PREFETCH && full_tile) {
+      if (PREFETCH && (full_tile || epi_vec)) {
 #pragma unroll
         for (int a = 0; a < NPRE; ++a)
           if (kt == a) {
@@ -624,6 +645,52 @@ __device__ __forceinline__ void gemm_tile(const GemmParams &p, float *lds, const
   KH_STAMP(5);
   // ---- epilogue: accumulator register r of lane (li, lh) is C[(r&3) + 8*(r>>2) + 4*lh][li] ------
   if constexpr (WK == 1) {
+    if (PREFETCH && epi_vec) {
+      // Vector form of the update epilogue.  Each wave turns its accumulators, one 32 x 32 block at a time, through
+      // a region of LDS of its own (the operand tiles are done with) so that a lane holds four consecutive columns
+      // of a row: the old weights came in, and the new ones (and the momentum buffer) go out, 16 bytes per lane,
+      // a wave instruction covering 8 whole 128-byte lines.  The new weights are stored write-through (sc1): they
+      // are not read again before the next forward pass, and 17 MB of dirty lines in L2 would otherwise be written
+      // back at the kernel's end, where the next launch waits for them (3-4 us per update launch measured).
+      // Same arithmetic, element for element, as epi_store<EPI_UPDATE>.
+      static_assert(!PREFETCH || 4 * 32 * 36 <= 2 * (A_ELEMS + B_ELEMS), "transposition areas larger than the tile buffers");
+      typedef int v4i_t __attribute__((ext_vector_type(4)));
+      const __amdgpu_buffer_rsrc_t rsrc_wout = __builtin_amdgcn_make_buffer_rsrc((void *)p.Wout, 0, p.wout_bytes, 0x00020000);
+      const __amdgpu_buffer_rsrc_t rsrc_c = __builtin_amdgcn_make_buffer_rsrc((void *)p.C, 0, p.c_bytes, 0x00020000);
+      float *xp = lds + wid * (32 * 36);
+      lds_barrier();  // every wave has read its last operand fragments
+#pragma unroll
+      for (int a = 0; a < TM * TN; ++a) {
+        if (a >= npre) prefetch_acc(a);  // (K shorter than the number of accumulators)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) xp[((r & 3) + 8 * (r >> 2) + 4 * lh) * 36 + li] = acc[a / TN][a % TN][r];
+        const int col = n0 + wn0 + (a % TN) * 32 + (lane & 7) * 4;
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+          const float4 v = *reinterpret_cast<const float4 *>(xp + ((lane >> 3) + 8 * pass) * 36 + (lane & 7) * 4);
+          float c[4] = {p.alpha * v.x, p.alpha * v.y, p.alpha * v.z, p.alpha * v.w};
+          if (p.mom != 0.f) {
+            const float4 o = buf_load(rsrc_c, vec_off(a, pass, p.ldc), 0);
+            c[0] += p.mom * o.x; c[1] += p.mom * o.y; c[2] += p.mom * o.z; c[3] += p.mom * o.w;
+          }
+          float w[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float wv = pre[PREFETCH ? a : 0][4 * pass + e];
+            if (p.l2 != 0.f) wv = -p.l2 * wv + wv;
+            w[e] = -p.lr * c[e] + wv;
+          }
+          if (col < p.N) {  // (rows past the matrix are dropped by the buffer bounds)
+            if (p.C) {
+              const v4i_t cv = {__float_as_int(c[0]), __float_as_int(c[1]), __float_as_int(c[2]), __float_as_int(c[3])};
+              __builtin_amdgcn_raw_buffer_store_b128(cv, rsrc_c, vec_off(a, pass, p.ldc), 0, 16);
+            }
+            const v4i_t wv4 = {__float_as_int(w[0]), __float_as_int(w[1]), __float_as_int(w[2]), __float_as_int(w[3])};
+            __builtin_amdgcn_raw_buffer_store_b128(wv4, rsrc_wout, vec_off(a, pass, p.ldwout), 0, 16);
+          }
+        }
+      }
+    } else
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
