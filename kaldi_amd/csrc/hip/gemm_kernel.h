@@ -74,7 +74,12 @@ void launch_reduce(hipStream_t st, const GemmParams &p, const float *slabs, int 
 // diagnostic build only: cycle stamps of wave 0 of every workgroup, 16 slots per workgroup
 #define KH_STAMP(i)                                                                     \
   do {                                                                                  \
-    if (p.stamps && threadIdx.x == 0) p.stamps[(size_t)blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime(); \
+    if (p.stamps && threadIdx.x == 0) {                                                 \
+      p.stamps[(size_t)blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime();           \
+      /* slots 8 / 9: the 100 MHz real-time counter (common to all XCDs) at entry and exit */ \
+      if ((i) == 0) p.stamps[(size_t)blockIdx.x * 16 + 8] = __builtin_amdgcn_s_memrealtime(); \
+      if ((i) == 7) p.stamps[(size_t)blockIdx.x * 16 + 9] = __builtin_amdgcn_s_memrealtime(); \
+    }                                                                                   \
   } while (0)
 #else
 #define KH_STAMP(i) do { } while (0)

@@ -299,6 +299,15 @@ __global__ void diff_xent_kernel(const int32_t *tgt, float *mat, float *log_post
 }
 
 // ---- fused Xent::EvalVec -------------------------------------------------------------------
+// Per-row results travel from the workgroup that made them to the one that adds them up inside one launch, so
+// they are stored write-through and loaded past the L1 (device-scope relaxed atomics = sc1 stores / loads): no
+// release / acquire fence is needed then, and a fence here would write back or invalidate a whole L2 while every
+// workgroup has just dirtied its row of the error matrix (the row kernel took 20 us at 256 x 9000 with fences).
+__device__ __forceinline__ void row_result_store(float *log_post, int32_t *max_id, int r, float lp, int32_t id) {
+  __hip_atomic_store(log_post + r, lp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(max_id + r, id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // pass 2: counters and loss in a fixed order, by one workgroup
 __device__ __forceinline__ void xent_accum_block(const int32_t *tgt, const float *log_post, const int32_t *max_id,
                                                  long long *counters, double *loss, int rows) {
@@ -310,8 +319,8 @@ __device__ __forceinline__ void xent_accum_block(const int32_t *tgt, const float
     double acc = 0.0;
     int correct = 0;
     for (int r = t; r < rows; r += 256) {
-      acc += (double)log_post[r];
-      correct += (max_id[r] == tgt[r]) ? 1 : 0;
+      acc += (double)__hip_atomic_load(log_post + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      correct += (__hip_atomic_load(max_id + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == tgt[r]) ? 1 : 0;
     }
     sd[t] = acc;
     sc[t] = correct;
@@ -330,10 +339,12 @@ __device__ __forceinline__ void xent_accum_block(const int32_t *tgt, const float
     loss[0] -= sd[0];
   }
 }
-// Called by every workgroup of a one-row-per-workgroup kernel after thread 0 stored the row's
-// results: the workgroup that arrives last (a device-scope counter, back at zero afterwards) runs
-// pass 2, so no second kernel sits on the stream between the loss and the first backward GEMM.
-// The sums are taken in the same order whichever workgroup that is.
+// Called by every workgroup of a one-row-per-workgroup kernel after thread 0 stored the row's results with
+// row_result_store: the workgroup that arrives last (a device-scope counter, back at zero afterwards) runs
+// pass 2, so no second kernel sits on the stream between the loss and the first backward GEMM.  Thread 0 waits for
+// its own write-through stores before it adds to the counter; the last arriver's other threads start loading
+// behind the workgroup barrier that follows thread 0's add.  The sums are taken in the same order whichever
+// workgroup that is.
 struct XentTail {
   unsigned *ticket;
   long long *counters;
@@ -342,11 +353,12 @@ struct XentTail {
 __device__ __forceinline__ void xent_finish(const XentTail &x, const int32_t *tgt, const float *log_post,
                                             const int32_t *max_id, int rows) {
   __shared__ unsigned arrived;
-  if (threadIdx.x == 0)
-    arrived = __hip_atomic_fetch_add(x.ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+  if (threadIdx.x == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this row's results have reached the L2
+    arrived = __hip_atomic_fetch_add(x.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
   __syncthreads();
   if (arrived != gridDim.x - 1) return;
-  __atomic_thread_fence(__ATOMIC_ACQUIRE);  // every thread of this workgroup reads the other rows' results
   xent_accum_block(tgt, log_post, max_id, x.counters, x.loss, rows);
   if (threadIdx.x == 0) __hip_atomic_store(x.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -370,10 +382,7 @@ __global__ __launch_bounds__(256) void xent_rows_kernel(const float *post, const
   } else if (threadIdx.x == 0 && t_ok) {
     q[t] = pt - 1.0f;
   }
-  if (threadIdx.x == 0) {
-    max_id[r] = b.i;
-    log_post[r] = logf(pt < 1e-20f ? 1e-20f : pt);
-  }
+  if (threadIdx.x == 0) row_result_store(log_post, max_id, r, logf(pt < 1e-20f ? 1e-20f : pt), b.i);
   xent_finish(tail, tgt, log_post, max_id, d.rows);
 }
 // pass 1, fast form: the row is read once with 16-byte loads into registers (NV float4 per thread,
@@ -452,9 +461,8 @@ __global__ __launch_bounds__(256) void xent_rows_vec_kernel(const float *post, c
       b = better(b, o);
       ptot += spt[w];
     }
-    max_id[r] = b.i;
     const float ptv = t_ok ? ptot : 0.0f;
-    log_post[r] = logf(ptv < 1e-20f ? 1e-20f : ptv);
+    row_result_store(log_post, max_id, r, logf(ptv < 1e-20f ? 1e-20f : ptv), b.i);
   }
   xent_finish(tail, tgt, log_post, max_id, d.rows);
 }
@@ -533,9 +541,8 @@ __global__ __launch_bounds__(kSoftmaxThreads) void softmax_xent_vec_kernel(float
       b = better(b, o);
       ptot += spt[w];
     }
-    xf.max_id[r] = b.i;
     const float ptv = t_ok ? ptot : 0.0f;
-    xf.log_post[r] = logf(ptv < 1e-20f ? 1e-20f : ptv);
+    row_result_store(xf.log_post, xf.max_id, r, logf(ptv < 1e-20f ? 1e-20f : ptv), b.i);
   }
   xent_finish(xf.tail, xf.tgt, xf.log_post, xf.max_id, xf.rows);
 }

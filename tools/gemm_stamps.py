@@ -44,9 +44,14 @@ fn = h.lib.hipK_gemm_stamps_read
 fn.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
 rc = fn(buf.ctypes.data, buf.size)
 assert rc == 0, rc
-st = buf.reshape(nblk, 16)[:, :8].astype(np.int64)
-st = st[st[:, 7] > 0]          # workgroups that are no GEMM tiles (bias workgroups) leave no stamps
+full = buf.reshape(nblk, 16).astype(np.int64)
+full = full[full[:, 7] > 0]    # workgroups that are no GEMM tiles (bias workgroups) leave no stamps
+st = full[:, :8]
 nblk = st.shape[0]
+rt0, rt1 = full[:, 8], full[:, 9]
+print("real time (100 MHz counter, common to all workgroups): first entry -> last exit %.2f us; entries spread over %.2f us, "
+      "exits over %.2f us; median workgroup lifetime %.2f us" % ((rt1.max() - rt0.min()) / 100.0, (rt0.max() - rt0.min()) / 100.0,
+                                                                 (rt1.max() - rt1.min()) / 100.0, np.median(rt1 - rt0) / 100.0))
 tm = h.Timer(None)
 tm.start()
 for _ in range(50):
