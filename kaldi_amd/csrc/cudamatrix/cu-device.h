@@ -65,21 +65,12 @@ class CuDevice {
     return aux_stream_;
   }
   /// A stream for host-to-device uploads that should run beside the training kernels (the tools'
-  /// feature uploads); same rules as the side stream.
+  /// feature uploads); same rules as the side stream.  Nothing on the device ever waits for it: the host does.
+  /// (Streams may be created in any order.  A hang that once depended on this stream being created before
+  /// the update streams came from a null-stream hipMemset in the device library's launch path, not from here.)
   khStream_t CopyStream() {
     EnsureInit();
-    if (copy_stream_ == NULL) {
-      // Created after the other two, whatever the order of first use.  Measured, not understood: with the
-      // copy stream created first (and the update streams at the first Backpropagate, as before), the
-      // second cache fill of the training tool never returned from synchronising the main stream, with
-      // 4 and with 8 hardware queues (tools/hang_probe.py reproduces it).  This stream only carries copies
-      // the host waits for; nothing on the device ever waits for it.
-      if (getenv("KALDI_AMD_COPY_STREAM_FIRST") == NULL) {  // (the variable: to reproduce the hang)
-        SideStream();
-        AuxStream();
-      }
-      CU_SAFE_CALL(hipK_stream_create(&copy_stream_));
-    }
+    if (copy_stream_ == NULL) CU_SAFE_CALL(hipK_stream_create(&copy_stream_));
     return copy_stream_;
   }
   /// `waiter` continues only after everything queued on `done` so far has finished (no host wait).

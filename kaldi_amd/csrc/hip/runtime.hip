@@ -37,10 +37,14 @@ int stream_ticket(hipStream_t st, unsigned **ticket) {
   if (rc != KH_OK) return rc;
   if (!w->ticket) {
     KH_HIP(hipMalloc((void **)&w->ticket, 256));
-    // Zeroed ON the stream whose kernels use it: hipMemset works on the null stream, with which a
-    // non-blocking stream has no ordering, and is not guaranteed to have finished when it returns
-    // (the first kernels then saw the allocation's old contents, nobody was "last", and the sums of
-    // those bunches were dropped).
+    // Zeroed ON the stream whose kernels use it.  This used to be a hipMemset, the library's only operation on
+    // the null stream, and it had two effects.  A non-blocking stream has no ordering with the null stream and
+    // the fill is not guaranteed to have finished when hipMemset returns: the first loss kernels of a process
+    // could see the allocation's old contents, no workgroup was "last", and the sums of those bunches were
+    // dropped (5 of 40 short tool runs).  And with priority streams on 4 hardware queues, the copy stream created
+    // before the update streams, a training tool never came back from synchronising its main stream at the second
+    // cache fill (3 of 3 runs with the null-stream fill, 0 of 5 without, same settings otherwise).  The library now
+    // issues nothing on the null stream.
     KH_HIP(hipMemsetAsync(w->ticket, 0, 256, st));
   }
   *ticket = w->ticket;

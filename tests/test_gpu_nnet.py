@@ -263,6 +263,28 @@ def test_train_tool_matches_reference(hip, nn, tmp_path, name, opts):
                 np.testing.assert_allclose(a.b, b.b, rtol=5e-5, atol=5e-6)
 
 
+@pytest.mark.parametrize("queues", ["4", "8"])
+def test_train_tool_with_update_streams_and_few_hardware_queues(hip, nn, tmp_path, queues):
+    """The configuration in which a training tool once never came back from synchronising its main stream at the second
+    cache fill: priority streams, the copy stream created before the update streams (the tool's uploader runs
+    first), updates on their own streams (KALDI_AMD_OVERLAP_UPDATES), 4 or 8 hardware queues.  The cause was a
+    hipMemset on the null stream in the device library's launch path (runtime.hip, stream_ticket); with every
+    memory operation ordered on the library's own streams the run finishes and matches the reference."""
+    g = load("train_e2e_small.npz")
+    (tmp_path / "m.nnet").write_bytes(g["model"].tobytes())
+    (tmp_path / "f.ark").write_bytes(g["feats_ark"].tobytes())
+    (tmp_path / "a.ark").write_bytes(g["ali_ark_txt"].tobytes())
+    exe = os.path.join(nn.BIN_DIR, "nnet-train-xent-hardlab-frmshuff")
+    env = dict(os.environ, KALDI_AMD_OVERLAP_UPDATES="1", GPU_MAX_HW_QUEUES=queues)
+    r = subprocess.run([exe, "--bunchsize=16", "--cachesize=64", "--binary=true", "--randomize=false",
+                        "ark:" + str(tmp_path / "f.ark"), "ark:" + str(tmp_path / "a.ark"), str(tmp_path / "m.nnet"),
+                        str(tmp_path / "out.nnet")], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=60, env=env)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    m = re.search(r"Xent:(\S+) frames:(\d+)", r.stderr.decode())
+    assert int(m.group(2)) == int(g["norand_frames"])
+    _model_close(tmp_path / "out.nnet", g["norand_model_out"].tobytes())
+
+
 def _model_close(path, ref_bytes, rtol=5e-5, atol=5e-6):
     got, ref = O.read_nnet(path.read_bytes()), O.read_nnet(ref_bytes)
     assert [l.marker for l in got] == [l.marker for l in ref]
