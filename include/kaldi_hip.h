@@ -105,6 +105,12 @@ int hipK_memset_async(khStream_t s, void *ptr, int value, size_t bytes); /* cuda
 int hipK_memcpy_2d(khStream_t s, void *dst, size_t dpitch, const void *src, size_t spitch,
                    size_t width_bytes, size_t height, int kind);
 int hipK_memcpy(khStream_t s, void *dst, const void *src, size_t bytes, int kind);
+/* The same 2-D copy, only queued on `s`: the host does not wait.  The host side must be pinned memory from
+ * hipK_malloc_host and belongs to the copy until an event recorded on `s` after this call has completed.  The
+ * reference's copies all block (cu-matrix-inl.h:173-222); nnet-forward uses this one to bring the posteriors
+ * of one utterance to the host while the next utterance is computed (nnetbin/nnet-forward.cc:127-160). */
+int hipK_memcpy_2d_async(khStream_t s, void *dst, size_t dpitch, const void *src, size_t spitch,
+                         size_t width_bytes, size_t height, int kind);
 
 /* ------------------------------------------------------------------------------------------
  * int32 kernels
@@ -116,6 +122,10 @@ int hipI32_set_const(khStream_t s, int32_t *mat, int32_t value, MatrixDim d);
  * float kernels: CuMatrix   (cu-kernels-ansi.h:44-67; kernels cu-kernels.cu:120-454)
  * ------------------------------------------------------------------------------------------ */
 int hipF_set_const(khStream_t s, float *mat, float value, MatrixDim d);
+/* counts[0] = number of NaN elements, counts[1] = number of +infinity elements of mat (counts: 2 int32 in
+ * device memory, zeroed and filled on `s`).  The reference scans every output matrix for exactly these two on
+ * the host, after the copy (nnetbin/nnet-forward.cc:147-156); here the scan runs where the matrix already is. */
+int hipF_count_nonfinite(khStream_t s, const float *mat, MatrixDim d, int32_t *counts);
 int hipF_part_set_const(khStream_t s, float *mat, float value, MatrixDim d, int32_t ro, int32_t r,
                         int32_t co, int32_t c);
 int hipF_binarize(khStream_t s, float *mat, float thres, MatrixDim d);

@@ -241,6 +241,41 @@ __global__ __launch_bounds__(256) void row_l2upperbound_kernel(float *mat, float
   }
 }
 
+// Counts the NaN and the +infinity elements of a matrix: counts[0] += #NaN, counts[1] += #(+inf).  A lane keeps
+// its own tallies, a wave adds them up with one ballot-free shuffle tree and only a wave that found something
+// touches the counters, so a clean matrix costs one streaming read and no atomics.
+__global__ void count_nonfinite_kernel(const float *mat, MatrixDim d, int *counts) {
+  int n_nan = 0, n_inf = 0;
+  const float inf = __builtin_inff();
+  const bool vec = (d.stride % 4 == 0) && ((reinterpret_cast<size_t>(mat) & 15) == 0);
+  for (int r = blockIdx.x; r < d.rows; r += gridDim.x) {
+    const float *row = mat + (size_t)r * d.stride;
+    int c0 = 0;
+    if (vec) {
+      const int nv = d.cols / 4;
+      for (int v = threadIdx.x; v < nv; v += blockDim.x) {
+        const float4 x = reinterpret_cast<const float4 *>(row)[v];
+        n_nan += (x.x != x.x) + (x.y != x.y) + (x.z != x.z) + (x.w != x.w);
+        n_inf += (x.x == inf) + (x.y == inf) + (x.z == inf) + (x.w == inf);
+      }
+      c0 = nv * 4;
+    }
+    for (int c = c0 + threadIdx.x; c < d.cols; c += blockDim.x) {
+      const float x = row[c];
+      n_nan += (x != x);
+      n_inf += (x == inf);
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    n_nan += __shfl_down(n_nan, off, 64);
+    n_inf += __shfl_down(n_inf, off, 64);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    if (n_nan) atomicAdd(&counts[0], n_nan);
+    if (n_inf) atomicAdd(&counts[1], n_inf);
+  }
+}
+
 dim3 grid2d(int cols, int rows) {
   int gx = (cols + 255) / 256;
   int gy = rows < 1 ? 1 : rows;
@@ -257,6 +292,18 @@ KH_EXPORT int hipI32_set_const(khStream_t s, int32_t *mat, int32_t value, Matrix
   if (d.rows == 0 || d.cols == 0) return KH_OK;
   KH_REQUIRE(mat != nullptr);
   hipLaunchKernelGGL(set_const_i32_kernel, grid2d(d.cols, d.rows), dim3(256), 0, kh::pick(s), mat, value, d);
+  return kh::launch_status();
+}
+
+KH_EXPORT int hipF_count_nonfinite(khStream_t s, const float *mat, MatrixDim d, int32_t *counts) {
+  KH_CHECK_INIT();
+  KH_REQUIRE(kh::dim_ok(d) && counts != nullptr);
+  hipStream_t st = kh::pick(s);
+  KH_HIP(hipMemsetAsync(counts, 0, 2 * sizeof(int32_t), st));
+  if (d.rows == 0 || d.cols == 0) return KH_OK;
+  KH_REQUIRE(mat != nullptr);
+  const int blocks = d.rows < 2048 ? d.rows : 2048;
+  hipLaunchKernelGGL(count_nonfinite_kernel, dim3(blocks), dim3(256), 0, st, mat, d, counts);
   return kh::launch_status();
 }
 

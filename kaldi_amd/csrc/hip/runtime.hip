@@ -404,6 +404,22 @@ KH_EXPORT int hipK_memcpy_2d(khStream_t s, void *dst, size_t dpitch, const void 
   return KH_OK;
 }
 
+// The copy is only queued: `s` runs it in order with its other work and the host goes on.  The host side must be
+// pinned memory (hipK_malloc_host); it may be read (D2H) or reused (H2D) once an event recorded on `s` after
+// this call has completed.
+KH_EXPORT int hipK_memcpy_2d_async(khStream_t s, void *dst, size_t dpitch, const void *src, size_t spitch,
+                                   size_t width_bytes, size_t height, int kind) {
+  KH_CHECK_INIT();
+  if (width_bytes == 0 || height == 0) return KH_OK;
+  KH_REQUIRE(dst && src && kind >= 0 && kind <= 2 && dpitch >= width_bytes && spitch >= width_bytes);
+  hipStream_t st = kh::pick(s);
+  if (dpitch == width_bytes && spitch == width_bytes)
+    KH_HIP(hipMemcpyAsync(dst, src, width_bytes * height, to_kind(kind), st));  // one contiguous block
+  else
+    KH_HIP(hipMemcpy2DAsync(dst, dpitch, src, spitch, width_bytes, height, to_kind(kind), st));
+  return KH_OK;
+}
+
 KH_EXPORT int hipK_memcpy(khStream_t s, void *dst, const void *src, size_t bytes, int kind) {
   KH_CHECK_INIT();
   if (bytes == 0) return KH_OK;

@@ -63,21 +63,31 @@ class Matrix {
     std::swap(cols_, o->cols_);
   }
 
-  void Write(std::ostream &os, bool binary) const {
+  void Write(std::ostream &os, bool binary) const { WriteData(os, binary, Data(), rows_, cols_, cols_); }
+  /// Writes rows x cols values, row r starting at data + r * stride, in the format of Write
+  /// (kaldi-matrix.cc:1213-1251): lets a caller that holds the values elsewhere (a pinned download buffer
+  /// laid out like the device matrix) write them without a Matrix.
+  static void WriteData(std::ostream &os, bool binary, const Real *data, MatrixIndexT rows, MatrixIndexT cols,
+                        MatrixIndexT stride) {
     if (!os.good()) KALDI_ERR << "Failed to write matrix to stream: stream not good";
     if (binary) {
       WriteToken(os, binary, sizeof(Real) == 4 ? "FM" : "DM");
-      WriteBasicType(os, binary, static_cast<int32>(rows_));
-      WriteBasicType(os, binary, static_cast<int32>(cols_));
-      os.write(reinterpret_cast<const char *>(Data()), sizeof(Real) * data_.size());
-    } else if (cols_ == 0) {
+      WriteBasicType(os, binary, static_cast<int32>(rows));
+      WriteBasicType(os, binary, static_cast<int32>(cols));
+      if (stride == cols) {
+        os.write(reinterpret_cast<const char *>(data), sizeof(Real) * static_cast<size_t>(rows) * cols);
+      } else {
+        for (MatrixIndexT r = 0; r < rows; ++r)
+          os.write(reinterpret_cast<const char *>(data + static_cast<size_t>(r) * stride), sizeof(Real) * cols);
+      }
+    } else if (cols == 0) {
       os << " [ ]\n";
     } else {
       os << " [";
-      for (MatrixIndexT r = 0; r < rows_; ++r) {
+      for (MatrixIndexT r = 0; r < rows; ++r) {
         os << "\n  ";
-        const Real *row = RowData(r);
-        for (MatrixIndexT c = 0; c < cols_; ++c) os << row[c] << " ";
+        const Real *row = data + static_cast<size_t>(r) * stride;
+        for (MatrixIndexT c = 0; c < cols; ++c) os << row[c] << " ";
       }
       os << "]\n";
     }

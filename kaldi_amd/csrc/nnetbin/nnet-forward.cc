@@ -2,27 +2,22 @@
 // checks, log lines and exit status of the reference tool (nnetbin/nnet-forward.cc:27-182); with
 // --num-ranks > 1 the utterances are sharded over the ranks (balanced by frames, no communication)
 // and "JOB" in the wspecifier is replaced by rank+1.
+//
+// The reference handles one utterance at a time from the read to the write.  Here three threads and two
+// copy streams work on different utterances at once: a reader thread reads ahead, this thread uploads an
+// utterance and queues its kernels, and the outputs travel to the host and into the table behind it
+// (PosteriorWriter).  Every utterance is still computed on its own, by the same kernels as before, so the
+// values written do not depend on what else is in flight.
 #include <limits>
 
 #include "base/kaldi-common.h"
 #include "cudamatrix/cu-device.h"
 #include "nnet/nnet-nnet.h"
 #include "nnetbin/dist-utils.h"
+#include "nnetbin/feature-upload.h"
+#include "nnetbin/posterior-download.h"
 #include "util/common-utils.h"
 #include "util/timer.h"
-
-namespace {
-void CheckFinite(const kaldi::Matrix<kaldi::BaseFloat> &m, const char *what, const std::string &key) {
-  using kaldi::BaseFloat;
-  for (kaldi::int32 r = 0; r < m.NumRows(); ++r) {
-    const BaseFloat *row = m.RowData(r);
-    for (kaldi::int32 c = 0; c < m.NumCols(); ++c) {
-      if (row[c] != row[c]) KALDI_ERR << "NaN in " << what << " of : " << key;
-      if (row[c] == std::numeric_limits<BaseFloat>::infinity()) KALDI_ERR << "inf in " << what << " of : " << key;
-    }
-  }
-}
-}  // namespace
 
 int main(int argc, char *argv[]) {
   using namespace kaldi;
@@ -77,11 +72,11 @@ int main(int argc, char *argv[]) {
     const int32 my_rank = dist.rank;
     PrefetchingBaseFloatMatrixReader feature_reader(
         feature_rspecifier, [&shard, my_rank](const std::string &, int32 rows) { return shard.Assign(rows) == my_rank; });
-    // writes behind on a thread of its own, which also scans every output for NaN / inf first
-    AsyncBaseFloatMatrixWriter feature_writer(
-        feature_wspecifier, 3, [](const std::string &key, const Matrix<BaseFloat> &m) { CheckFinite(m, "NNet output", key); });
+    // outputs are scanned for NaN / inf on the GPU, copied and written behind this thread
+    PosteriorWriter feature_writer(feature_wspecifier);
+    FeatureUploader uploader(8192);
 
-    CuMatrix<BaseFloat> feats, feats_transf, nnet_out;
+    CuMatrix<BaseFloat> feats_transf;
 
     // class priors from frame counts: log-domain offset or linear-domain scale
     Vector<BaseFloat> tmp_priors;
@@ -107,18 +102,17 @@ int main(int argc, char *argv[]) {
     int32 num_done = 0;
     for (; !feature_reader.Done(); feature_reader.Next()) {
       const Matrix<BaseFloat> &mat = feature_reader.Value();
-      CheckFinite(mat, "features", feature_reader.Key());
-      feats.CopyFromMat(mat);
+      const CuMatrix<BaseFloat> &feats = uploader.Upload(mat);
       nnet_transf.Feedforward(feats, &feats_transf);
-      nnet.Feedforward(feats_transf, &nnet_out);
-      if (apply_log) nnet_out.ApplyLog();
+      CuMatrix<BaseFloat> *nnet_out = feature_writer.Begin(mat.NumRows(), nnet.LayerCount() > 0 ? nnet.OutputDim() : feats_transf.NumCols());
+      if (nnet.LayerCount() > 0) nnet.Feedforward(feats_transf, nnet_out);
+      else if (nnet_out->NumRows() > 0) nnet_out->CopyFromMat(feats_transf, 0, feats_transf.NumRows(), 0, feats_transf.NumCols());
+      if (apply_log) nnet_out->ApplyLog();
       if (class_frame_counts != "") {
-        if (apply_log || no_softmax) nnet_out.AddVecToRows(1.0, priors, 1.0);
-        else nnet_out.MulColsVec(priors);
+        if (apply_log || no_softmax) nnet_out->AddVecToRows(1.0, priors, 1.0);
+        else nnet_out->MulColsVec(priors);
       }
-      Matrix<BaseFloat> *nnet_out_host = feature_writer.Acquire();
-      nnet_out.CopyToMat(nnet_out_host);
-      feature_writer.Submit(feature_reader.Key(), nnet_out_host);
+      feature_writer.Submit(feature_reader.Key(), feats);
       if (num_done % 1000 == 0 && !silent) KALDI_LOG << num_done << ", " << std::flush;
       num_done++;
       tot_t += mat.NumRows();

@@ -1,0 +1,216 @@
+// Network outputs on their way from the GPU into a table, beside the computation of the next utterances.
+//
+// The reference copies every output matrix to the host with a blocking copy, scans it for NaN / inf and
+// writes it, all on the thread that drives the GPU (nnetbin/nnet-forward.cc:127-160): per frame that is
+// 36 KB of output against 5 KB of input for a 9000-state network, and the GPU idles meanwhile.  Here the
+// caller computes each utterance into one of a few device slots (Begin), and Submit queues behind that
+// computation, without waiting: a count of the NaN / +inf elements of the input and of the output, run where
+// the matrices already are, and a copy of the output into pinned host memory on a stream of its own.  A
+// writer thread waits for each copy in submission order, raises the reference's error if a count is not
+// zero, writes the matrix from the pinned buffer and frees the slot.  An error on that thread surfaces at
+// the next Begin / Close.
+#ifndef KALDI_AMD_NNETBIN_POSTERIOR_DOWNLOAD_H_
+#define KALDI_AMD_NNETBIN_POSTERIOR_DOWNLOAD_H_
+#include <algorithm>
+#include <condition_variable>
+#include <deque>
+#include <exception>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "cudamatrix/cu-matrix.h"
+#include "util/common-utils.h"
+
+namespace kaldi {
+
+class PosteriorWriter {
+ public:
+  explicit PosteriorWriter(const std::string &wspecifier, size_t num_slots = 4)
+      : writer_(wspecifier), slots_(num_slots), cur_(NULL), stream_(NULL), stop_(false) {
+    CU_SAFE_CALL(hipK_stream_create(&stream_));
+    for (size_t i = 0; i < slots_.size(); ++i) {
+      Slot &s = slots_[i];
+      CU_SAFE_CALL(hipK_event_create(&s.computed));
+      CU_SAFE_CALL(hipK_event_create(&s.copied));
+      void *p = NULL;
+      CU_SAFE_CALL(hipK_malloc(&p, 256));
+      s.dev_counts = static_cast<int32_t *>(p);
+      CU_SAFE_CALL(hipK_malloc_host(&p, 256));
+      s.host_counts = static_cast<int32_t *>(p);
+      free_.push_back(&s);
+    }
+    thread_ = std::thread(&PosteriorWriter::Run, this);
+  }
+  ~PosteriorWriter() {
+    try {
+      Close();
+    } catch (...) {
+    }
+    CuDevice::Instantiate().Synchronize();
+    if (stream_) hipK_stream_synchronize(stream_);
+    for (size_t i = 0; i < slots_.size(); ++i) {
+      Slot &s = slots_[i];
+      s.view.Destroy();
+      hipK_free(s.dev);
+      hipK_free_host(s.host);
+      hipK_free(s.dev_counts);
+      hipK_free_host(s.host_counts);
+      hipK_event_destroy(s.computed);
+      hipK_event_destroy(s.copied);
+    }
+    if (stream_) hipK_stream_destroy(stream_);
+  }
+
+  /// A rows x cols device matrix to compute the next utterance's output into, with the row pitch of any
+  /// other CuMatrix of that width; waits for a free slot.  Write into it as it is: a Resize to another shape
+  /// would let go of the slot's memory.
+  CuMatrix<BaseFloat> *Begin(int32 rows, int32 cols) {
+    KALDI_ASSERT(cur_ == NULL && rows >= 0 && cols >= 0);
+    Slot *s;
+    {
+      std::unique_lock<std::mutex> l(mu_);
+      cv_free_.wait(l, [this] { return !free_.empty() || error_; });
+      Rethrow();
+      s = free_.front();  // oldest first: its memory has been idle the longest
+      free_.pop_front();
+    }
+    s->rows = rows;
+    s->cols = cols;
+    s->stride = static_cast<int32>(((static_cast<size_t>(cols) * sizeof(BaseFloat) + 255) & ~static_cast<size_t>(255)) / sizeof(BaseFloat));
+    const size_t dev_bytes = static_cast<size_t>(rows) * s->stride * sizeof(BaseFloat);
+    const size_t host_bytes = dev_bytes;  // the host copy keeps the device layout: one block to copy
+    // a free slot has no work pending on its memory: its last copy was waited for before it was written
+    if (dev_bytes > s->dev_cap) {
+      CU_SAFE_CALL(hipK_free(s->dev));
+      s->dev = NULL;
+      s->dev_cap = Headroom(dev_bytes);
+      void *p = NULL;
+      CU_SAFE_CALL(hipK_malloc(&p, s->dev_cap));
+      s->dev = static_cast<BaseFloat *>(p);
+    }
+    if (host_bytes > s->host_cap) {
+      CU_SAFE_CALL(hipK_free_host(s->host));
+      s->host = NULL;
+      s->host_cap = Headroom(host_bytes);
+      void *p = NULL;
+      CU_SAFE_CALL(hipK_malloc_host(&p, s->host_cap));
+      s->host = static_cast<BaseFloat *>(p);
+    }
+    s->view.AttachView(s->dev, rows, cols, s->stride);
+    cur_ = s;
+    return &s->view;
+  }
+
+  /// The main stream's work queued so far fills the matrix Begin handed out, from `input` (the features
+  /// it was computed from; may be empty).  Queues the scans and the copy behind it and returns.
+  void Submit(const std::string &key, const CuMatrix<BaseFloat> &input) {
+    KALDI_ASSERT(cur_ != NULL);
+    Slot *s = cur_;
+    cur_ = NULL;
+    s->key = key;
+    CuDevice &dev = CuDevice::Instantiate();
+    khStream_t main = dev.MainStream();
+    CU_SAFE_CALL(hipF_count_nonfinite(main, input.Data(), input.Dim(), s->dev_counts));
+    ::MatrixDim d = {s->rows, s->cols, s->stride};
+    CU_SAFE_CALL(hipF_count_nonfinite(main, s->dev, d, s->dev_counts + 2));
+    CU_SAFE_CALL(hipK_event_record(s->computed, main));
+    CU_SAFE_CALL(hipK_stream_wait_event(stream_, s->computed));
+    CU_SAFE_CALL(hipK_memcpy_2d_async(stream_, s->host_counts, 16, s->dev_counts, 16, 16, 1, 1));
+    const size_t pitch = s->stride * sizeof(BaseFloat);
+    CU_SAFE_CALL(hipK_memcpy_2d_async(stream_, s->host, pitch, s->dev, pitch, pitch, s->rows, 1));
+    CU_SAFE_CALL(hipK_event_record(s->copied, stream_));
+    std::lock_guard<std::mutex> l(mu_);
+    queue_.push_back(s);
+    cv_work_.notify_one();
+  }
+
+  /// writes everything submitted so far, stops the thread and closes the table
+  bool Close() {
+    if (thread_.joinable()) {
+      {
+        std::lock_guard<std::mutex> l(mu_);
+        stop_ = true;
+      }
+      cv_work_.notify_all();
+      thread_.join();
+    }
+    {
+      std::lock_guard<std::mutex> l(mu_);
+      Rethrow();
+    }
+    return writer_.IsOpen() ? writer_.Close() : true;
+  }
+
+ private:
+  struct Slot {
+    BaseFloat *dev = NULL, *host = NULL;
+    size_t dev_cap = 0, host_cap = 0;
+    int32_t *dev_counts = NULL, *host_counts = NULL;  // NaN, +inf of the input; NaN, +inf of the output
+    khEvent_t computed = NULL, copied = NULL;
+    int32 rows = 0, cols = 0, stride = 0;
+    std::string key;
+    CuMatrix<BaseFloat> view;
+  };
+  static size_t Headroom(size_t bytes) { return std::max<size_t>(bytes + bytes / 4, static_cast<size_t>(16) << 20); }
+  void Rethrow() {
+    if (error_) {
+      std::exception_ptr e = error_;
+      error_ = nullptr;
+      std::rethrow_exception(e);
+    }
+  }
+  void WriteOne(Slot *s) {
+    CU_SAFE_CALL(hipK_event_synchronize(s->copied));
+    // the reference's messages, features first (nnetbin/nnet-forward.cc:116-123, 147-156)
+    if (s->host_counts[0]) KALDI_ERR << "NaN in features of : " << s->key;
+    if (s->host_counts[1]) KALDI_ERR << "inf in features of : " << s->key;
+    if (s->host_counts[2]) KALDI_ERR << "NaN in NNet output of : " << s->key;
+    if (s->host_counts[3]) KALDI_ERR << "inf in NNet output of : " << s->key;
+    const BaseFloat *data = s->host;
+    const int32 rows = s->rows, cols = s->cols, stride = s->stride;
+    writer_.WriteWith(s->key, [data, rows, cols, stride](std::ostream &os, bool binary) {
+      InitKaldiOutputStream(os, binary);
+      Matrix<BaseFloat>::WriteData(os, binary, data, rows, cols, stride);
+      return os.good();
+    });
+  }
+  void Run() {
+    for (;;) {
+      Slot *s;
+      {
+        std::unique_lock<std::mutex> l(mu_);
+        cv_work_.wait(l, [this] { return !queue_.empty() || stop_; });
+        if (queue_.empty()) return;
+        s = queue_.front();
+        queue_.pop_front();
+      }
+      try {
+        WriteOne(s);
+      } catch (...) {
+        hipK_event_synchronize(s->copied);  // the slot's memory must be idle before it is handed out again
+        std::lock_guard<std::mutex> l(mu_);
+        if (!error_) error_ = std::current_exception();
+      }
+      std::lock_guard<std::mutex> l(mu_);
+      free_.push_back(s);
+      cv_free_.notify_one();
+    }
+  }
+
+  BaseFloatMatrixWriter writer_;
+  std::vector<Slot> slots_;
+  Slot *cur_;
+  khStream_t stream_;
+  std::mutex mu_;
+  std::condition_variable cv_free_, cv_work_;
+  std::deque<Slot *> free_, queue_;
+  std::exception_ptr error_;
+  bool stop_;
+  std::thread thread_;
+  KALDI_DISALLOW_COPY_AND_ASSIGN(PosteriorWriter);
+};
+
+}  // namespace kaldi
+#endif

@@ -429,13 +429,20 @@ class TableWriter {
   }
   bool IsOpen() const { return type_ != kNoWspecifier; }
   void Write(const std::string &key, const T &value) {
+    WriteWith(key, [&value](std::ostream &os, bool binary) { return Holder::Write(os, binary, value); });
+  }
+  /// The entry for `key` with its value written by `payload(stream, binary)` (false = failure): for a caller
+  /// whose value is not held in a T, e.g. matrix rows in a download buffer.  It must write what Holder::Write
+  /// would have written for that value.
+  typedef std::function<bool(std::ostream &, bool)> PayloadWriter;
+  void WriteWith(const std::string &key, const PayloadWriter &payload) {
     if (!IsToken(key)) KALDI_ERR << "TableWriter: using invalid key " << key;
     bool ok = true;
     if (type_ == kScriptWspecifier) {
       std::unordered_map<std::string, std::string>::iterator it = script_map_.find(key);
       if (it == script_map_.end()) KALDI_ERR << "TableWriter: key " << key << " not present in script file " << script_name_;
       Output out;
-      ok = out.Open(it->second, opts_.binary, false) && Holder::Write(out.Stream(), opts_.binary, value) && out.Close();
+      ok = out.Open(it->second, opts_.binary, false) && payload(out.Stream(), opts_.binary) && out.Close();
     } else {
       std::ostream &os = archive_.Stream();
       os << key << ' ';
@@ -443,7 +450,7 @@ class TableWriter {
         os.flush();
         script_.Stream() << key << ' ' << archive_name_ << ':' << static_cast<long long>(os.tellp()) << '\n';
       }
-      ok = Holder::Write(os, opts_.binary, value);
+      ok = payload(os, opts_.binary);
       if (opts_.flush) {
         os.flush();
         if (type_ == kBothWspecifier) script_.Stream().flush();

@@ -595,3 +595,27 @@ def test_argument_checks(hip):
     # empty matrices are a no-op
     assert h.lib.hipF_sigmoid(None, None, None, h.MatrixDim(0, 0, 0)) == 0
     assert h.lib.hipF_softmax(None, None, None, h.MatrixDim(0, 5, 5)) == 0
+
+
+@pytest.mark.parametrize("rows,cols", [(1, 1), (7, 50), (300, 9000), (4100, 33), (64, 2048)])
+def test_count_nonfinite(hip, rows, cols):
+    """hipF_count_nonfinite = the two host scans of nnet-forward (NaN, +inf; -inf is not counted there either,
+    nnetbin/nnet-forward.cc:147-156), on pitched and on dense rows, and on a clean matrix."""
+    h = hip
+    rs = np.random.RandomState(rows * 7 + cols)
+    x = rs.standard_normal((rows, cols)).astype(f32)
+    cnt = h.DevMatrix(1, 2, np.int32, pitched=False)
+    dx = dev(h, x)
+    h.call("hipF_count_nonfinite", None, dx.ptr, dx.dim, cnt.ptr)
+    assert cnt.numpy().ravel().tolist() == [0, 0]
+    n = rows * cols
+    flat = x.reshape(-1)
+    k_nan, k_inf, k_ninf = min(n, 5), min(max(n - 5, 0), 3), min(max(n - 8, 0), 2)
+    pos = rs.permutation(n)
+    flat[pos[:k_nan]] = np.nan
+    flat[pos[k_nan:k_nan + k_inf]] = np.inf
+    flat[pos[k_nan + k_inf:k_nan + k_inf + k_ninf]] = -np.inf
+    for pitched in (True, False):
+        dx = dev(h, x, pitched)
+        h.call("hipF_count_nonfinite", None, dx.ptr, dx.dim, cnt.ptr)
+        assert cnt.numpy().ravel().tolist() == [k_nan, k_inf]

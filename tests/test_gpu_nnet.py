@@ -229,6 +229,43 @@ def test_forward_tool_matches_reference(hip, nn, tmp_path):
     assert "NaN in features of : bad" in err
 
 
+def test_forward_tool_pipeline_ragged_utterances(hip, nn, tmp_path):
+    """nnet-forward keeps several utterances in flight (upload, kernels, download, write): 40 utterances of 1..900
+    frames, more than it has buffers, widths that are and are not a multiple of 4, against the numpy oracle; and
+    the same utterances in the opposite order give the same bits per utterance.  A network whose output
+    overflows is reported as the reference reports it (nnetbin/nnet-forward.cc:147-156)."""
+    rs = np.random.RandomState(91)
+    for out_dim in (52, 50):
+        dims = [40, 64, out_dim]
+        layers = []
+        for i in range(len(dims) - 1):
+            layers.append(O.BiasedLinearity((rs.randn(dims[i + 1], dims[i]) * 0.3).astype(f32), (rs.randn(dims[i + 1]) * 0.1).astype(f32)))
+            layers.append(O.Softmax(dims[i + 1]) if i == len(dims) - 2 else O.Sigmoid(dims[i + 1]))
+        (tmp_path / "m.nnet").write_bytes(O.write_nnet(layers, True))
+        lens = [int(v) for v in rs.randint(1, 901, 40)]
+        utts = [("u%02d" % i, rs.randn(t, dims[0]).astype(f32)) for i, t in enumerate(lens)]
+        (tmp_path / "a.ark").write_bytes(O.write_matrix_ark(utts))
+        (tmp_path / "b.ark").write_bytes(O.write_matrix_ark(utts[::-1]))
+        for n in "ab":
+            run_tool(nn, "nnet-forward", ["--silent=true", str(tmp_path / "m.nnet"), "ark:" + str(tmp_path / (n + ".ark")),
+                                          "ark:" + str(tmp_path / ("o%s.ark" % n))])
+        got_a = O.read_matrix_ark((tmp_path / "oa.ark").read_bytes())
+        got_b = dict(O.read_matrix_ark((tmp_path / "ob.ark").read_bytes()))
+        assert [k for k, _ in got_a] == [k for k, _ in utts]
+        net = O.Nnet(layers)
+        for (k, m), (_, x) in zip(got_a, utts):
+            assert m.shape == (x.shape[0], out_dim)
+            np.testing.assert_allclose(m, net.feedforward(x), rtol=1e-4, atol=2e-6)
+            assert np.array_equal(m, got_b[k])
+    # a linear output that overflows to +inf
+    big = [O.BiasedLinearity(np.full((8, 40), 3e38, f32), np.zeros(8, f32))]
+    (tmp_path / "big.nnet").write_bytes(O.write_nnet(big, True))
+    (tmp_path / "p.ark").write_bytes(O.write_matrix_ark([("ok", np.zeros((5, 40), f32)), ("pos", np.full((5, 40), 10, f32))]))
+    _, err = run_tool(nn, "nnet-forward", ["--no-softmax=true", str(tmp_path / "big.nnet"), "ark:" + str(tmp_path / "p.ark"),
+                                           "ark:" + str(tmp_path / "po.ark")], 255)
+    assert "inf in NNet output of : pos" in err
+
+
 @pytest.mark.parametrize("name,opts", [
     ("norand", ["--randomize=false"]),
     ("rand", []),

@@ -54,10 +54,13 @@ def run(cmd):
 
 
 bindir = os.path.join(ROOT, "kaldi_amd", "bin")
-print("nnet-train-xent-hardlab-frmshuff:")
-run([os.path.join(bindir, "nnet-train-xent-hardlab-frmshuff"), "--learn-rate=0.008", "--binary=true"] + extra + ["ark:" + feats,
-     "ark:" + ali, model, os.path.join(tmp, "out.nnet")])
-print("nnet-forward:")
+if os.environ.get("TOOL_FPS_SKIP_TRAIN") != "1":
+    print("nnet-train-xent-hardlab-frmshuff:")
+    run([os.path.join(bindir, "nnet-train-xent-hardlab-frmshuff"), "--learn-rate=0.008", "--binary=true"] + extra + ["ark:" + feats,
+         "ark:" + ali, model, os.path.join(tmp, "out.nnet")])
+print("nnet-forward -> ark:/dev/null:")
+run([os.path.join(bindir, "nnet-forward")] + extra + [model, "ark:" + feats, "ark:/dev/null"])
+print("nnet-forward -> ark file in %s:" % tmp)
 run([os.path.join(bindir, "nnet-forward")] + extra + [model, "ark:" + feats, "ark:" + os.path.join(tmp, "post.ark")])
 for f in os.listdir(tmp):
     os.remove(os.path.join(tmp, f))
