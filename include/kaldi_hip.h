@@ -320,6 +320,12 @@ int hipF_affine_apply(khStream_t s, int32_t O, int32_t I, const float *grad, int
                       float gscale, float momentum, float lr, float l2, float *W, int32_t ldw, float *corr,
                       int32_t ldcorr, float *bias, float *bcorr);
 
+/* The same step on `count` consecutive floats of a weight matrix's memory, taken as one long row (row padding
+ * included: gradient 0 there): for a rank that steps only its shard of a layer.  corr may be NULL only when
+ * momentum == 0.  Element for element the arithmetic of hipF_affine_apply. */
+int hipF_sgd_apply_flat(khStream_t s, size_t count, const float *grad, float gscale, float momentum, float lr,
+                        float l2, float *w, float *corr);
+
 /* Xent::EvalVec on the device (nnet-loss.cc:59-94 = cu::FindRowMaxId + host compare +
  * cu::DiffXent + host sum), one pass over the posteriors:
  *   diff = post - onehot(tgt)           (diff may alias post)
@@ -397,6 +403,19 @@ int hipF_allreduce_sum(khStream_t s, float *buf, size_t count);
 /* all-gather on stream s: every rank contributes `count` floats, recv receives nranks * count (rank r's block at
  * r * count); send may be recv + rank * count */
 int hipF_allgather(khStream_t s, const float *send, float *recv, size_t count);
+/* Sharded exchange for data-parallel training (no counterpart in the reference, which trains on one GPU).  A
+ * buffer of nranks * shard_count floats is cut into one shard per rank, shard r at offset r * shard_count:
+ *   hipF_reduce_scatter_sum  in place; afterwards this rank's shard holds the sum over ranks (the other shards
+ *                            are undefined)
+ *   hipK_comm_shard_range    the elements this process must step: its own shard -- every shard for the loopback
+ *                            stand-in, which plays all the ranks
+ *   hipF_allgather_shards    in place; every rank sends its shard, afterwards all hold the whole buffer
+ * hipK_comm_group_begin/end bracket collectives that may be sent as one launch (ncclGroupStart/End). */
+int hipK_comm_group_begin(void);
+int hipK_comm_group_end(void);
+int hipK_comm_shard_range(size_t shard_count, size_t *first, size_t *count);
+int hipF_reduce_scatter_sum(khStream_t s, float *buf, size_t shard_count);
+int hipF_allgather_shards(khStream_t s, float *buf, size_t shard_count);
 int hipK_allreduce_sum_f64(khStream_t s, double *buf, size_t count);
 int hipK_allreduce_sum_i64(khStream_t s, long long *buf, size_t count);
 /* in-place all-reduce of count int64 with op 0 = sum, 1 = min, 2 = max (control-plane scalars:

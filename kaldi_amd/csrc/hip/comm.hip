@@ -136,6 +136,60 @@ KH_EXPORT int hipF_allgather(khStream_t s, const float *send, float *recv, size_
   return KH_OK;
 }
 
+// ---- sharded exchange: reduce-scatter, step on the own shard, all-gather ------------------------
+// A buffer of nranks * shard_count elements is cut into one shard per rank, shard r at r * shard_count.
+KH_EXPORT int hipK_comm_group_begin(void) {
+  Comm &c = comm();
+  if (c.loopback || !c.comm) return KH_OK;
+  KH_NCCL(ncclGroupStart());
+  return KH_OK;
+}
+KH_EXPORT int hipK_comm_group_end(void) {
+  Comm &c = comm();
+  if (c.loopback || !c.comm) return KH_OK;
+  KH_NCCL(ncclGroupEnd());
+  return KH_OK;
+}
+
+KH_EXPORT int hipK_comm_shard_range(size_t shard_count, size_t *first, size_t *count) {
+  KH_REQUIRE(first != nullptr && count != nullptr);
+  Comm &c = comm();
+  // the loopback stand-in plays every rank in turn, so it owns every shard
+  *first = c.loopback ? 0 : (size_t)c.rank * shard_count;
+  *count = c.loopback ? (size_t)c.nranks * shard_count : shard_count;
+  return KH_OK;
+}
+
+KH_EXPORT int hipF_reduce_scatter_sum(khStream_t s, float *buf, size_t shard_count) {
+  KH_CHECK_INIT();
+  if (shard_count == 0) return KH_OK;
+  KH_REQUIRE(buf != nullptr);
+  Comm &c = comm();
+  if (c.nranks == 1 && !(force_rccl() && c.comm)) return KH_OK;
+  if (c.loopback) {
+    // every replica holds the same values: each shard's sum is nranks times it
+    const size_t count = shard_count * c.nranks;
+    hipLaunchKernelGGL(scale_kernel<float>, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, kh::pick(s), buf, count,
+                       (float)c.nranks);
+    return kh::launch_status();
+  }
+  if (!c.comm) return KH_ERR_NOT_INITIALISED;
+  // in place: the receive buffer is this rank's shard of the send buffer
+  KH_NCCL(ncclReduceScatter(buf, buf + (size_t)c.rank * shard_count, shard_count, ncclFloat32, ncclSum, c.comm, kh::pick(s)));
+  return KH_OK;
+}
+
+KH_EXPORT int hipF_allgather_shards(khStream_t s, float *buf, size_t shard_count) {
+  KH_CHECK_INIT();
+  if (shard_count == 0) return KH_OK;
+  KH_REQUIRE(buf != nullptr);
+  Comm &c = comm();
+  if (c.loopback || (c.nranks == 1 && !(force_rccl() && c.comm))) return KH_OK;  // every shard is already here
+  if (!c.comm) return KH_ERR_NOT_INITIALISED;
+  KH_NCCL(ncclAllGather(buf + (size_t)c.rank * shard_count, buf, shard_count, ncclFloat32, c.comm, kh::pick(s)));
+  return KH_OK;
+}
+
 KH_EXPORT int hipK_allreduce_sum_f64(khStream_t s, double *buf, size_t count) {
   return allreduce<double>(s, buf, count, ncclFloat64);
 }

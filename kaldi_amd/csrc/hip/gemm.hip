@@ -83,7 +83,7 @@ Plan make_plan(int M, int N, int K, int num_cu, bool allow_split, bool always_sl
   Plan best = {0, 1, ((K + kBK - 1) / kBK) * kBK};
   double best_cost = 1e300;
   const int ncfg = (int)(sizeof(kCfgs) / sizeof(kCfgs[0]));
-  const double cyc_per_us = 2050.0;  // clock held under fp32 MFMA load
+  const double cyc_per_us = 2400.0;  // shader clock under sustained fp32 MFMA load (2.38-2.40 GHz by s_memtime / s_memrealtime)
   for (int c = 0; c < ncfg; ++c) {
     const TileCfg &t = kCfgs[c];
     if (t.wk > 1 && !allow_wk) continue;
@@ -382,6 +382,27 @@ KH_EXPORT int hipF_affine_apply(khStream_t s, int32_t O, int32_t I, const float 
                        l2, W, ldw, corr, ldcorr);
   hipLaunchKernelGGL(bias_apply_kernel, dim3((O + 255) / 256), dim3(256), 0, st, O, bgrad, gscale, momentum, lr, bias,
                      bcorr);
+  return kh::launch_status();
+}
+
+KH_EXPORT int hipF_sgd_apply_flat(khStream_t s, size_t count, const float *grad, float gscale, float momentum, float lr,
+                                  float l2, float *w, float *corr) {
+  KH_CHECK_INIT();
+  if (count == 0) return KH_OK;
+  KH_REQUIRE(grad && w && count < ((size_t)1 << 31));
+  KH_REQUIRE(momentum == 0.f || corr != nullptr);
+  const int n = (int)count;
+  const bool vec = (n % 4 == 0) && kh::aligned16(grad) && kh::aligned16(w) && (!corr || kh::aligned16(corr));
+  const int per = vec ? 4 : 1;
+  const int gx = (n + 256 * per - 1) / (256 * per);
+  hipStream_t st = kh::pick(s);
+  // one long row: the element-wise formulas do not look at the position
+  if (vec)
+    hipLaunchKernelGGL((affine_apply_kernel<4>), dim3(gx, 1), dim3(256), 0, st, 1, n, grad, n, gscale, momentum, lr, l2, w, n,
+                       corr, n);
+  else
+    hipLaunchKernelGGL((affine_apply_kernel<1>), dim3(gx, 1), dim3(256), 0, st, 1, n, grad, n, gscale, momentum, lr, l2, w, n,
+                       corr, n);
   return kh::launch_status();
 }
 

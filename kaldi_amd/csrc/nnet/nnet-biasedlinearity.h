@@ -173,6 +173,43 @@ class BiasedLinearity : public UpdatableComponent {
     if (l2_upper_bound_ > 0.0) linearity_.ApplyRowL2UpperBound(l2_upper_bound_);
   }
 
+  /// Sharded data-parallel form.  The layer's weights are exchanged as the memory of the weight matrix itself
+  /// (dim_out rows of Stride() floats, padding included), cut into one shard per rank: possible when that
+  /// length divides evenly into 16-byte aligned shards and the step is element-wise (no L1 pass).
+  size_t WeightSpan() const { return static_cast<size_t>(output_dim_) * linearity_.Stride(); }
+  bool CanShard(int32 nranks) const {
+    const size_t n = WeightSpan();
+    return l1_penalty_ == 0.0 && nranks >= 1 && n % nranks == 0 && (n / nranks) % 4 == 0 &&
+           linearity_corr_.Stride() == linearity_.Stride();
+  }
+  size_t ShardedGradientSize() const { return WeightSpan() + output_dim_; }
+  /// gW = err^T * input laid out like the weight matrix (the padding of grad_buf's rows must be zero and is
+  /// left alone), gb = colsum(err) behind it
+  void ComputeGradientPitched(const CuMatrix<BaseFloat> &input, const CuMatrix<BaseFloat> &err, BaseFloat *grad_buf) {
+    CuProfileScope p("BiasedLinearity::ComputeGradient");
+    const int32 n = input.NumRows();
+    CU_SAFE_CALL(hipF_gemm(S(), KH_TRANS, KH_NO_TRANS, output_dim_, input_dim_, n, 1.0f, err.Data(), err.Stride(),
+                           input.Data(), input.Stride(), 0.0f, grad_buf, linearity_.Stride()));
+    CU_SAFE_CALL(hipF_add_row_sum_mat(S(), 1.0f, err.Data(), err.Dim(), 0.0f, grad_buf + WeightSpan()));
+  }
+  /// The step on elements [first, first + count) of the weight memory from the summed gradient at the same
+  /// positions of grad_buf, and on the whole bias from the summed bias gradient behind it.
+  void ApplyGradientRange(const BaseFloat *grad_buf, size_t first, size_t count, int32 total_frames) {
+    CuProfileScope p("BiasedLinearity::ApplyGradient");
+    KALDI_ASSERT(l1_penalty_ == 0.0 && first + count <= WeightSpan());
+    const BaseFloat gscale = average_grad_ ? 1.0 / total_frames : 1.0;
+    const BaseFloat l2 = (l2_penalty_ != 0.0) ? learn_rate_ * l2_penalty_ * total_frames : 0.0;
+    CU_SAFE_CALL(hipF_sgd_apply_flat(S(), count, grad_buf + first, gscale, momentum_, learn_rate_, l2,
+                                     linearity_.Data() + first, KeepCorr() ? linearity_corr_.Data() + first : NULL));
+    CU_SAFE_CALL(hipF_sgd_apply_flat(S(), output_dim_, grad_buf + WeightSpan(), gscale, momentum_, learn_rate_, 0.0f,
+                                     bias_.Data(), KeepCorr() ? bias_corr_.Data() : NULL));
+  }
+  /// after the shards of the new weights have been gathered
+  void FinishShardedStep() {
+    if (l2_upper_bound_ > 0.0) linearity_.ApplyRowL2UpperBound(l2_upper_bound_);
+  }
+  BaseFloat *WeightMemory() { return linearity_.Data(); }
+
   void SetLinearityWeight(const CuMatrix<BaseFloat> &weight, bool trans) {
     if (trans) {
       Matrix<BaseFloat> mat;

@@ -247,7 +247,8 @@ void Nnet::Backpropagate(const CuMatrix<BaseFloat> &in_err, CuMatrix<BaseFloat> 
         grad_events_.resize(L, NULL);
         read_events_.resize(L, NULL);
       }
-      const size_t need = bl->GradientSize();
+      const bool shard = dp_shard_ && bl->CanShard(dp_ranks_);
+      const size_t need = shard ? bl->ShardedGradientSize() : bl->GradientSize();
       if (need > dp_layer_grad_size_[i]) {
         if (dp_layer_grad_[i]) {
           CU_SAFE_CALL(hipK_device_synchronize());
@@ -257,17 +258,34 @@ void Nnet::Backpropagate(const CuMatrix<BaseFloat> &in_err, CuMatrix<BaseFloat> 
         CU_SAFE_CALL(hipK_malloc(&p, need * sizeof(BaseFloat)));
         dp_layer_grad_[i] = static_cast<BaseFloat *>(p);
         dp_layer_grad_size_[i] = need;
+        // (the sharded form relies on zeros in the padding of the gradient's rows)
+        CU_SAFE_CALL(hipK_memset_async(dev.SideStream(), p, 0, need * sizeof(BaseFloat)));
       }
       {
         CuStreamScope scope(dev.SideStream());
-        bl->ComputeGradient(input, err, dp_layer_grad_[i]);
+        if (shard) bl->ComputeGradientPitched(input, err, dp_layer_grad_[i]);
+        else bl->ComputeGradient(input, err, dp_layer_grad_[i]);
       }
       dev.Order(dev.SideStream(), dev.AuxStream(), &grad_events_[i]);
       dev.Order(dev.MainStream(), dev.AuxStream(), &read_events_[i]);
       {
         CuStreamScope scope(dev.AuxStream());
-        CU_SAFE_CALL(hipF_allreduce_sum(dev.AuxStream(), dp_layer_grad_[i], need));
-        bl->ApplyGradient(dp_layer_grad_[i], input.NumRows() * dp_ranks_);
+        if (shard) {
+          // weight gradient: every rank receives the sum of its shard; bias gradient (small): summed everywhere
+          const size_t span = bl->WeightSpan(), per_rank = span / dp_ranks_;
+          CU_SAFE_CALL(hipK_comm_group_begin());
+          CU_SAFE_CALL(hipF_reduce_scatter_sum(dev.AuxStream(), dp_layer_grad_[i], per_rank));
+          CU_SAFE_CALL(hipF_allreduce_sum(dev.AuxStream(), dp_layer_grad_[i] + span, bl->OutputDim()));
+          CU_SAFE_CALL(hipK_comm_group_end());
+          size_t first = 0, count = 0;
+          CU_SAFE_CALL(hipK_comm_shard_range(per_rank, &first, &count));
+          bl->ApplyGradientRange(dp_layer_grad_[i], first, count, input.NumRows() * dp_ranks_);
+          CU_SAFE_CALL(hipF_allgather_shards(dev.AuxStream(), bl->WeightMemory(), per_rank));
+          bl->FinishShardedStep();
+        } else {
+          CU_SAFE_CALL(hipF_allreduce_sum(dev.AuxStream(), dp_layer_grad_[i], need));
+          bl->ApplyGradient(dp_layer_grad_[i], input.NumRows() * dp_ranks_);
+        }
       }
       aux_used = true;
       return;
@@ -435,13 +453,22 @@ void Nnet::SetAverageGrad(bool flag) { KALDI_AMD_FOR_UPDATABLE(SetAverageGrad(fl
 void Nnet::SetDataParallel(int32 nranks) {
   KALDI_ASSERT(nranks >= 1);
   dp_ranks_ = nranks;
-  // Two exchanges give the same step.  Summing the per-layer gradients moves 2(n-1)/n x 185 MB per
-  // rank and step on the Switchboard net whatever the bunch; gathering every rank's rows of (layer
-  // input, layer error) moves (n-1) x 40 MB at a 256-frame bunch, and each rank then runs the
-  // single-GPU fused update on the n x 256 gathered rows (n times the update FLOPs, no gradient
-  // buffers, replicas identical by construction).  Few ranks: gather; many: sum.
+  // Three exchanges give the same step.
+  //  gather: every rank's rows of (layer input, layer error) are gathered -- (n-1) x 40 MB per rank and step on
+  //          the Switchboard net at a 256-frame bunch -- and each rank runs the single-GPU fused update on the
+  //          n x 256 rows (n times the update FLOPs, no gradient buffers, replicas identical by construction).
+  //  shard:  the per-layer gradients are summed by a reduce-scatter, each rank steps its 1/n of the layer and
+  //          the new weights are all-gathered in place: 2(n-1)/n x 185 MB over the links, as for an all-reduce,
+  //          but the post-exchange pass over gradient and weights shrinks to 1/n of the layer per rank.
+  //  sum:    all-reduce of the gradients, the whole step on every rank (kept for layers whose weight memory
+  //          does not cut evenly, and for comparison).
+  // Few ranks: gather; many: shard.
   dp_gather_ = nranks >= 2 && nranks <= 4;
-  if (const char *e = getenv("KALDI_AMD_DP_EXCHANGE")) dp_gather_ = nranks >= 2 && std::string(e) == "gather";
+  dp_shard_ = nranks > 4;
+  if (const char *e = getenv("KALDI_AMD_DP_EXCHANGE")) {
+    dp_gather_ = nranks >= 2 && std::string(e) == "gather";
+    dp_shard_ = nranks >= 2 && std::string(e) == "shard";
+  }
 }
 
 // ---- activations that look their buffers up in the owning network ------------------------------

@@ -79,8 +79,10 @@ class Nnet {
   /// The caller must then leave `in` alone until Backpropagate has returned.  Off by default.
   void SetBorrowInput(bool on) { borrow_input_ = on; }
   /// Synchronous data-parallel training over `nranks` processes (one GPU each, communicator set up
-  /// with hipK_comm_init): every <biasedlinearity> update becomes gradient -> sum all-reduce ->
-  /// identical step on every rank, equal to one process training on the concatenated bunch.
+  /// with hipK_comm_init): every <biasedlinearity> update becomes one exchange between the ranks and the
+  /// same new weights on all of them, equal to one process training on the concatenated bunch.  The
+  /// exchange (see SetDataParallel's definition) is chosen by the number of ranks; the environment variable
+  /// KALDI_AMD_DP_EXCHANGE = gather | shard | sum overrides it.
   void SetDataParallel(int32 nranks);
 
  private:
@@ -101,6 +103,7 @@ class Nnet {
   std::vector<khEvent_t> grad_events_;   // data-parallel: "local gradient of layer i complete"
   std::vector<khEvent_t> read_events_;   // data-parallel: "back-propagation of layer i has read its weights"
   bool dp_gather_ = false;  // data-parallel by gathering every rank's (input, error) rows instead of summing gradients
+  bool dp_shard_ = false;   // summed gradients, but each rank steps one shard of every layer and the new weights are gathered
   std::vector<CuMatrix<BaseFloat> > dp_in_all_, dp_err_all_;  // the gathered rows, per layer
   CuMatrix<BaseFloat> dp_in_repack_;
   std::vector<BaseFloat *> dp_layer_grad_;  // data-parallel: one gradient buffer per layer

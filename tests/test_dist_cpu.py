@@ -8,6 +8,9 @@
   * sharded nnet-forward: every rank evaluates the utterance -> rank rule on its own while streaming
     the same table; the ranks must agree, cover every utterance exactly once and balance frames.
   * per-cache bunch-count agreement (min over ranks), as used by the data-parallel training tool.
+  * the sharded exchange (KALDI_AMD_DP_EXCHANGE=shard): the gradient laid out like the pitched weight memory,
+    reduce-scatter, the step on the rank's own shard only, all-gather of the new weights -- must leave every
+    rank with the bits of the all-reduce form.
 """
 import os
 import socket
@@ -67,6 +70,49 @@ def _dp_step(net, x, tgt, world, allreduce, lr, mom, avg):
     return post
 
 
+def _dp_step_sharded(net, x, tgt, world, rank, reduce_to, allgather, allreduce, lr, mom, avg, state):
+    """The same step with the sharded exchange of Nnet::Backpropagate: per layer the weight memory (rows padded
+    to a multiple of 64 floats, as hipK_malloc_pitch lays them out) is cut into `world` shards; shard r of the
+    gradient is summed onto rank r, which steps only those elements; the new weights are then gathered."""
+    post = net.propagate(x)
+    err, _ = O.diff_xent(tgt, post)
+    buf = net.propagate_buf
+    cur = err
+    for i in range(len(net.layers) - 1, -1, -1):
+        l = net.layers[i]
+        below = l.backpropagate(cur, buf[i], buf[i + 1]) if i > 0 else None
+        if l.updatable:
+            rows, cols = l.W.shape
+            stride = (cols + 63) // 64 * 64
+            span = rows * stride
+            assert span % world == 0 and (span // world) % 4 == 0
+            per = span // world
+            if i not in state:   # pitched images of the weights and of the momentum state
+                wm, cm = np.zeros((rows, stride), f32), np.zeros((rows, stride), f32)
+                wm[:, :cols] = l.W
+                state[i] = (wm.reshape(-1), cm.reshape(-1))
+            wmem, cmem = state[i]
+            g2 = np.zeros((rows, stride), f32)
+            g2[:, :cols] = O.gemm(1.0, cur, True, buf[i], False, 0.0, None)
+            gflat = g2.reshape(-1)
+            gb = allreduce(O.add_row_sum_mat(1.0, cur, 0.0, np.zeros(l.dim_out, f32)))
+            mine = None
+            for r in range(world):   # reduce-scatter: shard r is summed onto rank r
+                got = reduce_to(gflat[r * per:(r + 1) * per], r)
+                if r == rank:
+                    mine = got
+            g = f32(1.0 / (x.shape[0] * world)) if avg else f32(1.0)
+            sl = slice(rank * per, (rank + 1) * per)
+            cmem[sl] = (g * mine + f32(mom) * cmem[sl]).astype(f32)
+            new_shard = (f32(-lr) * cmem[sl] + wmem[sl]).astype(f32)
+            wmem[:] = allgather(new_shard)             # every rank now holds the whole new weight memory
+            l.W = wmem.reshape(rows, stride)[:, :cols].copy()
+            l.b_corr = (g * gb + f32(mom) * l.b_corr).astype(f32)
+            l.b = (f32(-lr) * l.b_corr + l.b).astype(f32)
+        cur = below
+    return post
+
+
 def _worker(rank, world, port, q):
     import torch
     import torch.distributed as dist
@@ -89,6 +135,23 @@ def _worker(rank, world, port, q):
             _dp_step(net, xs, ts, world, allreduce, lr, mom, avg)
         params = np.concatenate([np.concatenate([l.W.ravel(), l.b]) for l in net.layers if l.updatable])
 
+        # the same three steps with the sharded exchange
+        def reduce_to(v, dst):
+            t = torch.from_numpy(v.copy())
+            dist.reduce(t, dst)
+            return t.numpy()
+
+        def allgather(v):
+            parts = [torch.zeros(v.size, dtype=torch.float32) for _ in range(world)]
+            dist.all_gather(parts, torch.from_numpy(v.copy()))
+            return np.concatenate([p_.numpy() for p_ in parts])
+
+        net2, state = _make_net(np.random.RandomState(7), dims), {}
+        for s in range(nsteps):
+            xs, ts = X[s, rank * nb:(rank + 1) * nb], T[s, rank * nb:(rank + 1) * nb]
+            _dp_step_sharded(net2, xs, ts, world, rank, reduce_to, allgather, allreduce, lr, mom, avg, state)
+        params_sharded = np.concatenate([np.concatenate([l.W.ravel(), l.b]) for l in net2.layers if l.updatable])
+
         # sharded forward: every rank evaluates the rule itself from the same table
         import kaldi_amd.nnet as nn
         lens = np.random.RandomState(3).randint(1, 900, 257)
@@ -101,7 +164,7 @@ def _worker(rank, world, port, q):
         # bunch-count agreement: every rank stops after the smallest count
         counts = torch.tensor([17 + 5 * rank], dtype=torch.int64)
         dist.all_reduce(counts, op=dist.ReduceOp.MIN)
-        q.put((rank, params, agree, my_frames, int(lens.sum()), int(counts.item())))
+        q.put((rank, params, agree, my_frames, int(lens.sum()), int(counts.item()), params_sharded))
     finally:
         dist.destroy_process_group()
 
@@ -134,6 +197,8 @@ def test_data_parallel_step_equals_single_process_and_shards_agree():
     ref = np.concatenate([np.concatenate([l.W.ravel(), l.b]) for l in net.layers if l.updatable])
 
     np.testing.assert_array_equal(res[0][1], res[1][1])                      # replicas stay identical
+    np.testing.assert_array_equal(res[0][6], res[1][6])                      # also with the sharded exchange,
+    np.testing.assert_array_equal(res[0][6], res[0][1])                      # which gives the all-reduce form's bits
     np.testing.assert_allclose(res[0][1], ref, rtol=2e-5, atol=2e-6)         # and match one big bunch
     assert res[0][2] and res[1][2]                                            # same shard map on every rank
     total = res[0][4]

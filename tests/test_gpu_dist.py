@@ -9,6 +9,7 @@
 import os
 import re
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -36,7 +37,7 @@ def _model_bytes(rs, dims):
 
 
 @pytest.mark.parametrize("mom,avg", [(0.0, True), (0.5, True), (0.0, False)])
-@pytest.mark.parametrize("exchange", ["sum", "gather"])
+@pytest.mark.parametrize("exchange", ["sum", "gather", "shard"])
 def test_data_parallel_path_equals_stacked_bunch(hip, nn, tmp_path, monkeypatch, mom, avg, exchange):
     rs = np.random.RandomState(11)
     dims = [40, 96, 64, 33]
@@ -172,7 +173,7 @@ def test_dp_tool_loop_uneven_shards_and_report_contract(hip, nn, tmp_path):
     assert (tmp_path / "out0.nnet").exists() and not (tmp_path / "out1.nnet").exists()   # rank 0 writes the model
 
 
-@pytest.mark.parametrize("exchange", ["sum", "gather"])
+@pytest.mark.parametrize("exchange", ["sum", "gather", "shard"])
 def test_data_parallel_three_steps_rm_shape_equal_oracle_on_stacked_bunch(hip, nn, tmp_path, monkeypatch, exchange):
     """The three-stream data-parallel step (gradient GEMMs, exchange and shared step beside the back-propagation) over
     three consecutive steps at the RM size, kernels long enough to overlap: two stand-in ranks on a bunch equal the
@@ -210,3 +211,46 @@ def test_data_parallel_three_steps_rm_shape_equal_oracle_on_stacked_bunch(hip, n
         dp.close()
     finally:
         hip.call("hipK_comm_destroy")
+
+
+@pytest.mark.parametrize("R", [2, 4, 5])
+def test_sharded_exchange_gives_the_bits_of_the_summed_one(hip, nn, tmp_path, monkeypatch, R):
+    """KALDI_AMD_DP_EXCHANGE=shard (reduce-scatter, step on the own shard, all-gather of the new weights) against
+    =sum (all-reduce, whole step everywhere): same weights, biases and momentum state bit for bit after three steps
+    with momentum, weight decay and the row-norm bound.  With 5 stand-in ranks two of the three layers do not cut
+    evenly and take the summed form inside a sharded run."""
+    rs = np.random.RandomState(77)
+    dims = [40, 96, 64, 33]
+    data, _ = _model_bytes(rs, dims)
+    model = tmp_path / "m.nnet"
+    model.write_bytes(data)
+    N, steps = 64, 3
+    X = rs.standard_normal((steps, N, dims[0])).astype(f32)
+    T = rs.randint(0, dims[-1], (steps, N)).astype(np.int32)
+    got = {}
+    hip.call("hipK_comm_init_loopback", R)
+    try:
+        for exchange in ("sum", "shard"):
+            monkeypatch.setenv("KALDI_AMD_DP_EXCHANGE", exchange)
+            dp = nn.Trainer(str(model))
+            dp.set_train_opts(0.05, 0.7, 1e-4, 0.0, 1.5, True, True)
+            dp.set_data_parallel(R)
+            for s_ in range(steps):
+                x, t = hip.DevMatrix.from_numpy(X[s_]), hip.DevMatrix.from_numpy(T[s_], pitched=False)
+                dp.train_bunch(x.ptr, x.stride, N, dims[0], t.ptr)
+            got[exchange] = [dp.layer_params(i, dims[i // 2 + 1], dims[i // 2]) for i in (0, 2, 4)]
+            dp.close()
+    finally:
+        hip.call("hipK_comm_destroy")
+    for (Wa, ba), (Wb, bb) in zip(got["sum"], got["shard"]):
+        assert np.array_equal(Wa, Wb) and np.array_equal(ba, bb)
+    assert not np.array_equal(got["sum"][0][0], np.zeros_like(got["sum"][0][0]))
+
+
+def test_rccl_entry_points_with_one_rank(nn):
+    """Every collective of the library through RCCL itself, on a one-rank communicator (the box has one GPU):
+    all-reduce, all-gather, the grouped reduce-scatter + all-reduce and the in-place all-gather of the sharded
+    exchange, min / max, barrier."""
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "rccl_probe.py")], stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, timeout=110)
+    assert r.returncode == 0 and b"rccl probe ok" in r.stdout, r.stdout.decode()[-2000:]

@@ -33,6 +33,18 @@ assert (d.numpy()[0] == x).all()
 g = h.DevMatrix(1, x.size, np.float32, pitched=False)
 h.call("hipF_allgather", None, d.ptr, g.ptr, x.size)
 assert (g.numpy()[0] == x).all()
+# the sharded exchange: grouped reduce-scatter + all-reduce, step range, in-place all-gather
+y = np.arange(1 << 16, dtype=np.float32)
+e, bsum = h.DevMatrix.from_numpy(y, False), h.DevMatrix.from_numpy(y[:100].copy(), False)
+h.call("hipK_comm_group_begin")
+h.call("hipF_reduce_scatter_sum", None, e.ptr, y.size)
+h.call("hipF_allreduce_sum", None, bsum.ptr, 100)
+h.call("hipK_comm_group_end")
+first, count = ctypes.c_size_t(), ctypes.c_size_t()
+h.call("hipK_comm_shard_range", y.size, ctypes.byref(first), ctypes.byref(count))
+assert (first.value, count.value) == (0, y.size)
+h.call("hipF_allgather_shards", None, e.ptr, y.size)
+assert (e.numpy()[0] == y).all() and (bsum.numpy()[0] == y[:100]).all()
 v = h.DevMatrix.from_numpy(np.array([7], np.int64), False)
 h.call("hipK_allreduce_i64", None, v.ptr, 1, 1)
 assert int(v.numpy()[0, 0]) == 7
