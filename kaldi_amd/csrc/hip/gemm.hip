@@ -610,7 +610,7 @@ KH_EXPORT int hipF_affine_update_fused(khStream_t s, int32_t N, int32_t O, int32
   set_update_footprints(p);
   p.bias_io = bias;
   p.bcorr = bcorr;
-  p.bias_tiles = (O + 63) / 64;  // ride at the start of the GEMM's grid
+  p.bias_tiles = (O + 63) / 64;  // ride in the GEMM's launch
   return run_gemm<EPI_UPDATE>(s, false, false, p, /*allow_split=*/false);
 }
 

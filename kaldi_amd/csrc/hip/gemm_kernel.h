@@ -49,7 +49,7 @@ struct GemmParams {
   // EPI_UPDATE: footprints of W / Wout / C (< 2 GiB) when the epilogue may use 16-byte buffer accesses on them
   // (all 16-byte aligned, leading dimensions and N multiples of 4), else 0: see the epilogue
   int w_bytes, wout_bytes, c_bytes;
-  // EPI_UPDATE only: the bias half of the update, done by `bias_tiles` extra workgroups at the start of the grid
+  // EPI_UPDATE only: the bias half of the update, `bias_tiles` groups of 64 outputs done inside the launch
   // (bias_io -= lr * (alpha * colsum(A) + mom * bcorr); A is the error matrix, K x M as stored)
   float *bias_io;
   float *bcorr;
@@ -81,8 +81,14 @@ void launch_reduce(hipStream_t st, const GemmParams &p, const float *slabs, int 
       if ((i) == 7) p.stamps[(size_t)blockIdx.x * 16 + 9] = __builtin_amdgcn_s_memrealtime(); \
     }                                                                                   \
   } while (0)
+// real-time stamp into slot i (10..15) of the workgroup's 16
+#define KH_RT(i)                                                                                          \
+  do {                                                                                                    \
+    if (p.stamps && threadIdx.x == 0) p.stamps[(size_t)blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memrealtime(); \
+  } while (0)
 #else
 #define KH_STAMP(i) do { } while (0)
+#define KH_RT(i) do { } while (0)
 #endif
 
 // The epilogue's second operand of one output element, fetched before any store so that the
@@ -776,46 +782,74 @@ __device__ __forceinline__ void gemm_tile(const GemmParams &p, float *lds, const
 #endif
 }
 
-// Bias half of BiasedLinearity::Update for 64 outputs, by one 256-thread workgroup riding at the start of the
-// weight-update GEMM's grid (no launch of its own): bcorr = alpha * colsum(e) + mom * bcorr ; bias -= lr * bcorr.
+// Bias half of BiasedLinearity::Update for 64 outputs, by one 256-thread workgroup of the weight-update GEMM's
+// launch (no launch of its own): bcorr = alpha * colsum(e) + mom * bcorr ; bias -= lr * bcorr.
 // The sums are taken exactly like bias_update_kernel's (16 interleaved row groups, combined in order 0..15),
 // so both give the same bits.
 __device__ __forceinline__ void bias_update_tile(const GemmParams &p, float *lds, int tile) {
-  const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;  // q = 0..3: takes row groups q, q+4, q+8, q+12
-  const int c = tile * 64 + lane;
-  float acc[4] = {0.f, 0.f, 0.f, 0.f};
-  if (c < p.M) {
-    const float *e = p.A + c;
-    // 8 rows of each of this thread's 4 row groups per trip: 32 independent loads in flight, then the adds in
-    // row order (the order fixes the bits)
-    for (int r0 = q; r0 < p.K; r0 += 16 * 8) {
-      float x[4][8];
+  KH_RT(10);
+  const int tid = threadIdx.x;
+  if (p.a_bytes != 0 && (p.lda & 3) == 0 && (reinterpret_cast<size_t>(p.A) & 15) == 0) {
+    // Thread (g = tid / 16, quad = tid % 16) sums rows g, g + 16, g + 32, ... of 4 adjacent columns: one 16-byte
+    // buffer load per row, the 16 rows of a 256-frame bunch all in flight, added in row order.  Rows past K lie
+    // beyond the descriptor's range and load as 0; columns past M are summed (from padding or the next row)
+    // and never stored.  Kept short on purpose: the workgroup runs this once, cold in the instruction cache,
+    // beside workgroups that keep memory busy -- a fully unrolled form with a load per element (1200
+    // instructions) spent 14 us fetching its own code there (in-kernel stamps), this one is ~100 instructions.
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)p.A, 0, p.a_bytes, 0x00020000);
+    const int g = tid >> 4, quad = tid & 15;
+    const int voff = (g * p.lda + tile * 64 + quad * 4) * 4;
+    v4f acc = {0.f, 0.f, 0.f, 0.f};
+    for (int r0 = 0; r0 < p.K; r0 += 256) {
+      v4f x[16];
 #pragma unroll
-      for (int v = 0; v < 4; ++v)
+      for (int u = 0; u < 16; ++u)
+        x[u] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, (r0 + 16 * u) * p.lda * 4, 0));
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int r = r0 + 4 * v + 16 * u;
-          x[v][u] = (r < p.K) ? e[(size_t)r * p.lda] : 0.f;
-        }
-#pragma unroll
-      for (int v = 0; v < 4; ++v)
-#pragma unroll
-        for (int u = 0; u < 8; ++u)
-          if (r0 + 4 * v + 16 * u < p.K) acc[v] += x[v][u];
+      for (int u = 0; u < 16; ++u) acc += x[u];
     }
-  }
+    KH_RT(11);
+    *reinterpret_cast<v4f *>(&lds[g * 64 + quad * 4]) = acc;
+  } else {
+    // any layout: a load per element, thread (q = tid / 64, lane) takes row groups q, q + 4, q + 8, q + 12 of column lane
+    const int lane = tid & 63, q = tid >> 6;
+    const int c = tile * 64 + lane;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    if (c < p.M) {
+      const float *e = p.A + c;
+      for (int r0 = q; r0 < p.K; r0 += 16 * 8) {
+        float x[4][8];
 #pragma unroll
-  for (int v = 0; v < 4; ++v) lds[(q + 4 * v) * 64 + lane] = acc[v];
+        for (int v = 0; v < 4; ++v)
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int r = r0 + 4 * v + 16 * u;
+            x[v][u] = (r < p.K) ? e[(size_t)r * p.lda] : 0.f;
+          }
+#pragma unroll
+        for (int v = 0; v < 4; ++v)
+#pragma unroll
+          for (int u = 0; u < 8; ++u)
+            if (r0 + 4 * v + 16 * u < p.K) acc[v] += x[v][u];
+      }
+    }
+#pragma unroll
+    for (int v = 0; v < 4; ++v) lds[(q + 4 * v) * 64 + lane] = acc[v];
+  }
   __syncthreads();
-  if (q == 0 && c < p.M) {
+  KH_RT(12);
+  const int c = tile * 64 + tid;
+  if (tid < 64 && c < p.M) {
     float t = 0.f;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) t += lds[i * 64 + lane];
+    for (int i = 0; i < 16; ++i) t += lds[i * 64 + tid];
     float bc = p.alpha * t;
     if (p.mom != 0.f) bc += p.mom * p.bcorr[c];
     if (p.bcorr) p.bcorr[c] = bc;
     p.bias_io[c] = -p.lr * bc + p.bias_io[c];
   }
+  KH_RT(13);
 }
 
 template <int BM, int BN, int BK, int WK, bool A_KMAJOR, bool B_KMAJOR, int EPI, bool VEC>
@@ -823,13 +857,33 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
   __shared__ __attribute__((aligned(16))) float lds[gemm_lds_floats<BM, BN, BK, WK, A_KMAJOR, B_KMAJOR>()];
   if constexpr (EPI == EPI_UPDATE) {
     static_assert(gemm_lds_floats<BM, BN, BK, WK, A_KMAJOR, B_KMAJOR>() >= 16 * 64, "bias tile needs 1024 floats");
-    // the bias workgroups come first (p.bias_tiles rounded up to a multiple of 8 in the grid, so that the tile
-    // index below stays congruent to blockIdx.x modulo 8): they are short and finish while the GEMM tiles run
-    const int nbias = (p.bias_tiles + 7) & ~7;
-    if ((int)blockIdx.x < nbias) {
-      if ((int)blockIdx.x < p.bias_tiles) bias_update_tile(p, lds, blockIdx.x);
+    // The bias half of the update rides in this launch.  With 64-row tiles, one workgroup of every tile row
+    // takes the column sums of the error for its 64 outputs first (the columns it is about to stream as its A
+    // operand) and then goes on to its tile: it runs that much behind the workgroups it shares the compute unit
+    // with and catches up when they are done, so the launch ends barely later than without the sums.  (Tried
+    // and measured: workgroups of their own in front of the tiles held 32 of the 1024 workgroup slots that the
+    // tiles of a 2048 x 2048 layer fill exactly, and the 32 tiles left over started most of a workgroup lifetime
+    // late; at the end of the grid they start when the first tiles finish and add their whole 3.7 us -- kernel
+    // arguments, one round of loads, the exchange, the bias round trip -- to the launch.)  The chosen column
+    // walks with the row so that the carriers spread over the XCDs.  Other tile heights: workgroups at the end.
+    const int ntiles = p.tiles_m * p.tiles_n * p.splitk;
+    if (BM == 64) {
+      if (p.bias_tiles > 0) {
+        int L = blockIdx.x;  // same decode as gemm_tile
+        if ((ntiles & 7) == 0) L = (L & 7) * (ntiles >> 3) + (L >> 3);
+        const int mi = L % p.tiles_m;
+        L /= p.tiles_m;
+        const int ks = L % p.splitk, ni = L / p.splitk;
+        if (ks == 0 && ni == ((p.tiles_n >= 8) ? (mi & 7) * (p.tiles_n >> 3) : 0) && mi < p.bias_tiles) {
+          bias_update_tile(p, lds, mi);
+          __syncthreads();
+        }
+      }
+      gemm_tile<BM, BN, BK, WK, A_KMAJOR, B_KMAJOR, EPI, VEC>(p, lds, blockIdx.x, ntiles);
+    } else if ((int)blockIdx.x >= ntiles) {
+      bias_update_tile(p, lds, (int)blockIdx.x - ntiles);
     } else {
-      gemm_tile<BM, BN, BK, WK, A_KMAJOR, B_KMAJOR, EPI, VEC>(p, lds, blockIdx.x - nbias, (int)gridDim.x - nbias);
+      gemm_tile<BM, BN, BK, WK, A_KMAJOR, B_KMAJOR, EPI, VEC>(p, lds, blockIdx.x, ntiles);
     }
   } else {
     gemm_tile<BM, BN, BK, WK, A_KMAJOR, B_KMAJOR, EPI, VEC>(p, lds, blockIdx.x, gridDim.x);
@@ -862,7 +916,7 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(GemmParams p, const fl
 
 template <int BM, int BN, int WK, bool AK, bool BK_, int EPI>
 void launch_cfg(hipStream_t st, const GemmParams &p, bool vec) {
-  const int nblk = p.tiles_m * p.tiles_n * p.splitk + (EPI == EPI_UPDATE ? ((p.bias_tiles + 7) & ~7) : 0);
+  const int nblk = p.tiles_m * p.tiles_n * p.splitk + (EPI == EPI_UPDATE && BM != 64 ? p.bias_tiles : 0);
   if (vec)
     hipLaunchKernelGGL((gemm_kernel<BM, BN, kBK, WK, AK, BK_, EPI, true>), dim3(nblk), dim3(256), p.dyn_lds, st, p);
   else

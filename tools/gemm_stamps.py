@@ -34,7 +34,7 @@ def run():
         return (N + bm - 1) // bm * ((I + bn - 1) // bn) * sk
     h.call("hipF_affine_update", None, N, O_, I, e.ptr, e.stride, x.ptr, x.stride, f32(1), f32(0), f32(1e-9), f32(0),
            W.ptr, W.stride, None, 0, b.ptr, None)
-    return (O_ + bm - 1) // bm * ((I + bn - 1) // bn) * sk + (((O_ + 63) // 64 + 7) & ~7)   # + the bias workgroups in front
+    return (O_ + bm - 1) // bm * ((I + bn - 1) // bn) * sk
 
 
 for _ in range(20):
@@ -45,13 +45,26 @@ fn.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
 rc = fn(buf.ctypes.data, buf.size)
 assert rc == 0, rc
 full = buf.reshape(nblk, 16).astype(np.int64)
-full = full[full[:, 7] > 0]    # workgroups that are no GEMM tiles (bias workgroups) leave no stamps
+car = full[full[:, 10] > 0]
+if car.shape[0]:
+    t_first = full[:, 8].min()
+    c = (car[:, 10:14] - t_first) / 100.0
+    print("%d carriers of the bias sums (us after the first tile entry, median): start %.2f, sums done %.2f, exchanged %.2f, "
+          "bias written %.2f" % (car.shape[0], np.median(c[:, 0]), np.median(c[:, 1]), np.median(c[:, 2]), np.median(c[:, 3])))
 st = full[:, :8]
 nblk = st.shape[0]
 rt0, rt1 = full[:, 8], full[:, 9]
 print("real time (100 MHz counter, common to all workgroups): first entry -> last exit %.2f us; entries spread over %.2f us, "
       "exits over %.2f us; median workgroup lifetime %.2f us" % ((rt1.max() - rt0.min()) / 100.0, (rt0.max() - rt0.min()) / 100.0,
                                                                  (rt1.max() - rt1.min()) / 100.0, np.median(rt1 - rt0) / 100.0))
+late = rt0 - rt0.min()
+ids = np.arange(full.shape[0])
+print("entry delay percentiles (us) 50/90/99/100: %s; workgroups entering > 1 us late: %d" %
+      ("/".join("%.2f" % (np.percentile(late, q) / 100.0) for q in (50, 90, 99, 100)), int((late > 100).sum())))
+if (late > 100).any():
+    w = np.nonzero(late > 100)[0]
+    print("  late workgroups (grid index: delay us, lifetime us): " +
+          ", ".join("%d: %.1f, %.1f" % (ids[i], late[i] / 100.0, (rt1[i] - rt0[i]) / 100.0) for i in w[:24]))
 tm = h.Timer(None)
 tm.start()
 for _ in range(50):
