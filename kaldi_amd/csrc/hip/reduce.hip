@@ -128,48 +128,72 @@ __global__ __launch_bounds__(kSoftmaxThreads) void softmax_kernel(float *y, int 
 // aligned rows / slabs / bias and cols <= 4 * kSoftmaxThreads * NV.
 // The row in registers: v[] receives exp(x - max) of this thread's columns (0 past the end), the
 // return value is 1 / sum.
+// All accesses are 16-byte buffer loads / stores whose descriptor ends with the row's last whole group of 4
+// columns (rows are padded to a multiple of 4 floats; a 16-byte access that crosses the descriptor's end is out
+// of range as a whole): lanes past the end read 0 and write nothing, so there is no branch around any access
+// and the loads of a phase -- every slab and the bias -- are all in flight together.  (With a branch per
+// access, every guarded load became a memory round trip of its own.)  Columns of the last group that lie past
+// `cols` hold padding: they are masked out of max and sum and stored as 0.
+typedef int kh_v4i __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t row_rsrc(const float *p, int cols) {
+  return __builtin_amdgcn_make_buffer_rsrc((void *)p, 0, ((cols + 3) & ~3) * 4, 0x00020000);
+}
+__device__ __forceinline__ float4 row_load4(__amdgpu_buffer_rsrc_t rs, int c) {
+  const kh_v4i r = __builtin_amdgcn_raw_buffer_load_b128(rs, c * 4, 0, 0);
+  return make_float4(__int_as_float(r.x), __int_as_float(r.y), __int_as_float(r.z), __int_as_float(r.w));
+}
+__device__ __forceinline__ void row_store4(__amdgpu_buffer_rsrc_t rs, int c, float a, float b, float cc, float d) {
+  kh_v4i v = {__float_as_int(a), __float_as_int(b), __float_as_int(cc), __float_as_int(d)};
+  __builtin_amdgcn_raw_buffer_store_b128(v, rs, c * 4, 0, 0);
+}
 template <int NV>
 __device__ __forceinline__ float softmax_row_regs(float4 (&v)[NV], const float *px, int nslab, size_t slab_stride,
                                                   const float *bias, int cols, float *red) {
   const int t = threadIdx.x;
-  const int cols4 = (cols + 3) & ~3;  // whole float4s inside the padded row
+  const __amdgpu_buffer_rsrc_t rs0 = row_rsrc(px, cols);
 #pragma unroll
-  for (int k = 0; k < NV; ++k) {
-    const int c = (t + k * kSoftmaxThreads) * 4;
-    v[k] = (c < cols4) ? *reinterpret_cast<const float4 *>(px + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int k = 0; k < NV; ++k) v[k] = row_load4(rs0, (t + k * kSoftmaxThreads) * 4);
+  float4 b4[NV];
+  if (bias) {
+    // the bias vector is not padded: whole groups of 4 by the descriptor, a ragged end element by element
+    const int whole = cols & ~3;
+    const __amdgpu_buffer_rsrc_t rsb = row_rsrc(bias, whole);
+#pragma unroll
+    for (int k = 0; k < NV; ++k) b4[k] = row_load4(rsb, (t + k * kSoftmaxThreads) * 4);
+    if (cols != whole) {
+#pragma unroll
+      for (int k = 0; k < NV; ++k)
+        if ((t + k * kSoftmaxThreads) * 4 == whole) {
+          b4[k].x = bias[whole];
+          if (whole + 1 < cols) b4[k].y = bias[whole + 1];
+          if (whole + 2 < cols) b4[k].z = bias[whole + 2];
+        }
+    }
   }
-  for (int sl = 1; sl < nslab; ++sl) {
+  for (int sl = 1; sl < nslab; ++sl) {  // slabs in order, then the bias: the order of the sums fixes the bits
+    const __amdgpu_buffer_rsrc_t rs = row_rsrc(px + (size_t)sl * slab_stride, cols);
+    float4 a[NV];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) a[k] = row_load4(rs, (t + k * kSoftmaxThreads) * 4);
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
-      const int c = (t + k * kSoftmaxThreads) * 4;
-      if (c < cols4) {
-        const float4 a = *reinterpret_cast<const float4 *>(px + (size_t)sl * slab_stride + c);
-        v[k].x += a.x; v[k].y += a.y; v[k].z += a.z; v[k].w += a.w;
-      }
+      v[k].x += a[k].x; v[k].y += a[k].y; v[k].z += a[k].z; v[k].w += a[k].w;
     }
   }
   if (bias) {
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
-      const int c = (t + k * kSoftmaxThreads) * 4;
-      if (c + 3 < cols) {
-        const float4 a = *reinterpret_cast<const float4 *>(bias + c);
-        v[k].x += a.x; v[k].y += a.y; v[k].z += a.z; v[k].w += a.w;
-      } else if (c < cols) {
-        v[k].x += bias[c];
-        if (c + 1 < cols) v[k].y += bias[c + 1];
-        if (c + 2 < cols) v[k].z += bias[c + 2];
-      }
+      v[k].x += b4[k].x; v[k].y += b4[k].y; v[k].z += b4[k].z; v[k].w += b4[k].w;
     }
   }
   float mx = -INFINITY;
 #pragma unroll
   for (int k = 0; k < NV; ++k) {
     const int c = (t + k * kSoftmaxThreads) * 4;
-    if (c < cols) mx = fmaxf(mx, v[k].x);
-    if (c + 1 < cols) mx = fmaxf(mx, v[k].y);
-    if (c + 2 < cols) mx = fmaxf(mx, v[k].z);
-    if (c + 3 < cols) mx = fmaxf(mx, v[k].w);
+    mx = fmaxf(mx, (c < cols) ? v[k].x : -INFINITY);
+    mx = fmaxf(mx, (c + 1 < cols) ? v[k].y : -INFINITY);
+    mx = fmaxf(mx, (c + 2 < cols) ? v[k].z : -INFINITY);
+    mx = fmaxf(mx, (c + 3 < cols) ? v[k].w : -INFINITY);
   }
   mx = kh::block_max(mx, red);
   float sum = 0.f;
@@ -185,15 +209,6 @@ __device__ __forceinline__ float softmax_row_regs(float4 (&v)[NV], const float *
   sum = kh::block_sum(sum, red);
   return 1.0f / sum;
 }
-__device__ __forceinline__ void store_row4(float *py, int c, int cols, float a, float b, float cc, float d) {
-  if (c + 3 < cols) {
-    *reinterpret_cast<float4 *>(py + c) = make_float4(a, b, cc, d);
-  } else if (c < cols) {
-    py[c] = a;
-    if (c + 1 < cols) py[c + 1] = b;
-    if (c + 2 < cols) py[c + 2] = cc;
-  }
-}
 template <int NV>
 __global__ __launch_bounds__(kSoftmaxThreads) void softmax_vec_kernel(float *y, int ldy, const float *x, int ldx,
                                                                       int nslab, size_t slab_stride,
@@ -203,9 +218,10 @@ __global__ __launch_bounds__(kSoftmaxThreads) void softmax_vec_kernel(float *y, 
   float *py = y + (size_t)r * ldy;
   float4 v[NV];
   const float inv = softmax_row_regs<NV>(v, x + (size_t)r * ldx, nslab, slab_stride, bias, cols, red);
+  const __amdgpu_buffer_rsrc_t rsy = row_rsrc(py, cols);
 #pragma unroll
   for (int k = 0; k < NV; ++k)
-    store_row4(py, (threadIdx.x + k * kSoftmaxThreads) * 4, cols, v[k].x * inv, v[k].y * inv, v[k].z * inv, v[k].w * inv);
+    row_store4(rsy, (threadIdx.x + k * kSoftmaxThreads) * 4, v[k].x * inv, v[k].y * inv, v[k].z * inv, v[k].w * inv);
 }
 
 __global__ __launch_bounds__(256) void softmax_part_kernel(const float *X, const int32_t *ids, float *Y,
@@ -493,31 +509,31 @@ __global__ __launch_bounds__(kSoftmaxThreads) void softmax_xent_vec_kernel(float
   const float inv = softmax_row_regs<NV>(v, x + (size_t)r * ldx, nslab, slab_stride, bias, cols, red);
   const int t = xf.tgt[r];
   const bool t_ok = (t >= 0 && t < cols);
-  float *py = y + (size_t)r * ldy;
-  float *pd = xf.diff + (size_t)r * xf.lddiff;
+  const __amdgpu_buffer_rsrc_t rsy = row_rsrc(y + (size_t)r * ldy, xf.write_post ? cols : 0);  // 0 columns: nothing is written
+  const __amdgpu_buffer_rsrc_t rsd = row_rsrc(xf.diff + (size_t)r * xf.lddiff, cols);
   MaxId m;
   m.v = -1e21f;
   m.i = -1;
   float pt = 0.0f;
 #pragma unroll
   for (int k = 0; k < NV; ++k) {
+    // posterior = v * inv rounded, then - 1 at the target: two roundings, as when the posterior is read back
+    // from memory by the two-kernel form (a fused multiply-add here would differ in the last bit)
+#pragma clang fp contract(off)
     const int c = (threadIdx.x + k * kSoftmaxThreads) * 4;
     float e[4] = {v[k].x * inv, v[k].y * inv, v[k].z * inv, v[k].w * inv};
-    if (xf.write_post) store_row4(py, c, cols, e[0], e[1], e[2], e[3]);
+    row_store4(rsy, c, e[0], e[1], e[2], e[3]);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      if (c + j < cols) {
-        if (e[j] > m.v) {
-          m.v = e[j];
-          m.i = c + j;
-        }
-        if (c + j == t) {
-          pt = e[j];
-          e[j] -= 1.0f;
-        }
-      }
+      const bool in = c + j < cols;
+      const bool up = in && e[j] > m.v;  // ascending columns, strict: the first maximum stays
+      m.v = up ? e[j] : m.v;
+      m.i = up ? c + j : m.i;
+      const bool hit = in && (c + j == t);
+      pt = hit ? e[j] : pt;
+      e[j] = hit ? e[j] - 1.0f : e[j];
     }
-    store_row4(pd, c, cols, e[0], e[1], e[2], e[3]);
+    row_store4(rsd, c, e[0], e[1], e[2], e[3]);
   }
   m = wave_best(m);  // per-thread columns ascend, lower index wins ties: the first maximum of the row
 #pragma unroll
