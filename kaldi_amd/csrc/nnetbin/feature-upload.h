@@ -46,9 +46,8 @@ class FeatureUploader {
         nxt.Resize(std::max(rows, bank_rows_), mat.NumCols());
         dev.Synchronize();  // the zero fill was queued on the main stream
       } else if (consumed_[bank_]) {
-        // The host waits, not the copy stream: streams share a few hardware queues, and a copy
-        // stream parked on the main stream's event would hold up update kernels queued behind it
-        // in the same hardware queue -- which the main stream in turn waits for.
+        // The host waits, not the copy stream: it happens once per bank, and the copy stream stays
+        // free of waits on other streams (nothing it carries can then be held up by training work).
         CU_SAFE_CALL(hipK_event_synchronize(consumed_[bank_]));
       }
     }
