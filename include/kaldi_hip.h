@@ -296,6 +296,26 @@ int hipF_affine_update_fused(khStream_t s, int32_t N, int32_t O, int32_t I, cons
                              const float *W_in, int32_t ldw_in, float *W_out, int32_t ldw_out, float *corr,
                              int32_t ldcorr, float *bias, float *bcorr);
 
+/* The updates of several layers in ONE launch: item i is exactly one hipF_affine_update_fused call (same
+ * arguments, same bits), the items must not overlap in what they write.  For a training step that queues the
+ * updates of all its <biasedlinearity> layers behind the back-propagation pass (each BiasedLinearity::Update,
+ * nnet-biasedlinearity.h:71-102, needs only its layer's input, its output error and its own weights): a
+ * 256-frame update is short, so launched one by one every layer pays a kernel boundary and all its
+ * workgroups load, multiply and store in step; in one long grid the workgroups of a compute unit drift out
+ * of phase and one's loads and stores run under another's MFMAs.  Items that do not qualify for the
+ * grouped kernel (operands not 16-byte aligned, more than 2 GiB) are launched on their own. */
+typedef struct {
+  int32_t N, O, I;
+  const float *e; int32_t lde;
+  const float *in; int32_t ldin;
+  float gscale, momentum, lr, l2;
+  const float *W_in; int32_t ldw_in;
+  float *W_out; int32_t ldw_out;
+  float *corr; int32_t ldcorr;
+  float *bias; float *bcorr;
+} khAffineUpdate;
+int hipF_affine_update_group(khStream_t s, int32_t count, const khAffineUpdate *items);
+
 /* The two halves of hipF_affine_update on their own, so that a caller can queue them on different
  * streams (the bias half reads only e; the weight half reads only e and in besides W):
  *   weights: corr = gscale * e^T * in + momentum * corr ; W_out = (1 - l2) * W_in - lr * corr

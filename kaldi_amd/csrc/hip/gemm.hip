@@ -614,6 +614,67 @@ KH_EXPORT int hipF_affine_update_fused(khStream_t s, int32_t N, int32_t O, int32
   return run_gemm<EPI_UPDATE>(s, false, false, p, /*allow_split=*/false);
 }
 
+KH_EXPORT int hipF_affine_update_group(khStream_t s, int32_t count, const khAffineUpdate *items) {
+  KH_CHECK_INIT();
+  KH_REQUIRE(count >= 0 && (count == 0 || items != nullptr));
+  static const bool off = getenv("KALDI_HIP_NO_UPDATE_GROUP") != nullptr;  // for A/B measurements
+  hipStream_t st = kh::pick(s);
+  GemmGroup g;
+  memset(&g, 0, sizeof(g));
+  double flops = 0.0;
+  auto flush = [&]() -> int {
+    if (g.n == 0) return KH_OK;
+    {
+      TimedLaunch tl(st, flops);
+      launch_update_group(st, g);
+    }
+    g.n = 0;
+    g.first[0] = 0;
+    flops = 0.0;
+    return kh::launch_status();
+  };
+  for (int i = 0; i < count; ++i) {
+    const khAffineUpdate &u = items[i];
+    KH_REQUIRE(u.N > 0 && u.O > 0 && u.I > 0);
+    KH_REQUIRE(u.e && u.in && u.W_in && u.W_out && u.bias && u.lde >= u.O && u.ldin >= u.I && u.ldw_in >= u.I && u.ldw_out >= u.I);
+    KH_REQUIRE(u.momentum == 0.f || (u.corr != nullptr && u.bcorr != nullptr));
+    KH_REQUIRE(u.corr == nullptr || u.ldcorr >= u.I);
+    GemmParams p = base_params(u.O, u.I, u.N, u.e, u.lde, u.in, u.ldin, u.corr, u.ldcorr);
+    p.alpha = u.gscale;
+    p.mom = u.momentum;
+    p.lr = u.lr;
+    p.l2 = u.l2;
+    p.W = u.W_in;
+    p.ldw = u.ldw_in;
+    p.Wout = u.W_out;
+    p.ldwout = u.ldw_out;
+    set_update_footprints(p);
+    p.bias_io = u.bias;
+    p.bcorr = u.bcorr;
+    p.bias_tiles = (u.O + 63) / 64;
+    const bool vec = kh::aligned16(p.A) && kh::aligned16(p.B) && (p.lda % 4 == 0) && (p.ldb % 4 == 0);
+    Plan plan = {0, 1, ((p.K + kBK - 1) / kBK) * kBK};  // 64 x 64 tiles, K whole
+    apply_plan(p, plan, false, false);
+    if (off || !vec || p.a_bytes == 0 || force_bm > 0) {
+      // not for the grouped kernel: on its own, in order
+      int rc = flush();
+      if (rc != KH_OK) return rc;
+      rc = run_gemm<EPI_UPDATE>(s, false, false, p, /*allow_split=*/false);
+      if (rc != KH_OK) return rc;
+      continue;
+    }
+    g.p[g.n] = p;
+    const int blocks = p.tiles_m * p.tiles_n;
+    g.first[g.n + 1] = g.first[g.n] + ((blocks + 7) & ~7);
+    flops += 2.0 * p.M * p.N * p.K;
+    if (++g.n == kMaxGroup) {
+      const int rc = flush();
+      if (rc != KH_OK) return rc;
+    }
+  }
+  return flush();
+}
+
 KH_EXPORT int hipF_affine_update_bias(khStream_t s, int32_t N, int32_t O, const float *e, int32_t lde, float gscale,
                                       float momentum, float lr, float *bias, float *bcorr) {
   KH_CHECK_INIT();

@@ -1,5 +1,6 @@
 // Kernels of the fp32 MFMA GEMM for one epilogue (see gemm_kernel.h).
 #define KHG_DEFINE_KERNELS
+#define KHG_DEFINE_UPDATE_GROUP
 #include "gemm_kernel.h"
 
 namespace khg {

@@ -61,6 +61,18 @@ struct GemmParams {
 
 constexpr int kBK = 32;
 
+// Several weight-update products in ONE launch (64 x 64 tiles, both operands row-major as stored: e^T * in).
+// Problem i owns blocks [first[i], first[i + 1]); every first[i] is a multiple of 8, so a block keeps its residue
+// modulo 8 (its XCD under round-robin placement) inside its problem and the XCD-aware tile decode keeps its meaning;
+// blocks past a problem's tile count are padding and leave at once.
+constexpr int kMaxGroup = 8;
+struct GemmGroup {
+  int n;
+  int first[kMaxGroup + 1];
+  GemmParams p[kMaxGroup];
+};
+void launch_update_group(hipStream_t st, const GemmGroup &g);
+
 // launches the main kernel for tile configuration `cfg` (index into the planner's table) and operand layout
 template <int EPI>
 void launch_layout(hipStream_t st, const GemmParams &p, int cfg, bool vec, bool a_kmajor, bool b_kmajor);
@@ -852,34 +864,42 @@ __device__ __forceinline__ void bias_update_tile(const GemmParams &p, float *lds
   KH_RT(13);
 }
 
+// One 64-row tile of a weight update, and the bias half of the update where this workgroup carries it.
+// The bias half rides in the update's launch.  With 64-row tiles, one workgroup of every tile row
+// takes the column sums of the error for its 64 outputs first (the columns it is about to stream as its A
+// operand) and then goes on to its tile: it runs that much behind the workgroups it shares the compute unit
+// with and catches up when they are done, so the launch ends barely later than without the sums.  (Tried
+// and measured: workgroups of their own in front of the tiles held 32 of the 1024 workgroup slots that the
+// tiles of a 2048 x 2048 layer fill exactly, and the 32 tiles left over started most of a workgroup lifetime
+// late; at the end of the grid they start when the first tiles finish and add their whole 3.7 us -- kernel
+// arguments, one round of loads, the exchange, the bias round trip -- to the launch.)  The chosen column
+// walks with the row so that the carriers spread over the XCDs.
+template <int BM, int BN, int BK, int WK, bool A_KMAJOR, bool B_KMAJOR, int EPI, bool VEC>
+__device__ __forceinline__ void update_tile64(const GemmParams &p, float *lds, const int bid, const int ntiles) {
+  static_assert(BM == 64, "64-row tiles");
+  if (p.bias_tiles > 0) {
+    int L = bid;  // same decode as gemm_tile
+    if ((ntiles & 7) == 0) L = (L & 7) * (ntiles >> 3) + (L >> 3);
+    const int mi = L % p.tiles_m;
+    L /= p.tiles_m;
+    const int ks = L % p.splitk, ni = L / p.splitk;
+    if (ks == 0 && ni == ((p.tiles_n >= 8) ? (mi & 7) * (p.tiles_n >> 3) : 0) && mi < p.bias_tiles) {
+      bias_update_tile(p, lds, mi);
+      __syncthreads();
+    }
+  }
+  gemm_tile<BM, BN, BK, WK, A_KMAJOR, B_KMAJOR, EPI, VEC>(p, lds, bid, ntiles);
+}
+
 template <int BM, int BN, int BK, int WK, bool A_KMAJOR, bool B_KMAJOR, int EPI, bool VEC>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
   __shared__ __attribute__((aligned(16))) float lds[gemm_lds_floats<BM, BN, BK, WK, A_KMAJOR, B_KMAJOR>()];
   if constexpr (EPI == EPI_UPDATE) {
     static_assert(gemm_lds_floats<BM, BN, BK, WK, A_KMAJOR, B_KMAJOR>() >= 16 * 64, "bias tile needs 1024 floats");
-    // The bias half of the update rides in this launch.  With 64-row tiles, one workgroup of every tile row
-    // takes the column sums of the error for its 64 outputs first (the columns it is about to stream as its A
-    // operand) and then goes on to its tile: it runs that much behind the workgroups it shares the compute unit
-    // with and catches up when they are done, so the launch ends barely later than without the sums.  (Tried
-    // and measured: workgroups of their own in front of the tiles held 32 of the 1024 workgroup slots that the
-    // tiles of a 2048 x 2048 layer fill exactly, and the 32 tiles left over started most of a workgroup lifetime
-    // late; at the end of the grid they start when the first tiles finish and add their whole 3.7 us -- kernel
-    // arguments, one round of loads, the exchange, the bias round trip -- to the launch.)  The chosen column
-    // walks with the row so that the carriers spread over the XCDs.  Other tile heights: workgroups at the end.
+    // 64-row tiles: the bias half inside tile workgroups (update_tile64); other tile heights: workgroups at the end
     const int ntiles = p.tiles_m * p.tiles_n * p.splitk;
-    if (BM == 64) {
-      if (p.bias_tiles > 0) {
-        int L = blockIdx.x;  // same decode as gemm_tile
-        if ((ntiles & 7) == 0) L = (L & 7) * (ntiles >> 3) + (L >> 3);
-        const int mi = L % p.tiles_m;
-        L /= p.tiles_m;
-        const int ks = L % p.splitk, ni = L / p.splitk;
-        if (ks == 0 && ni == ((p.tiles_n >= 8) ? (mi & 7) * (p.tiles_n >> 3) : 0) && mi < p.bias_tiles) {
-          bias_update_tile(p, lds, mi);
-          __syncthreads();
-        }
-      }
-      gemm_tile<BM, BN, BK, WK, A_KMAJOR, B_KMAJOR, EPI, VEC>(p, lds, blockIdx.x, ntiles);
+    if constexpr (BM == 64) {
+      update_tile64<BM, BN, BK, WK, A_KMAJOR, B_KMAJOR, EPI, VEC>(p, lds, blockIdx.x, ntiles);
     } else if ((int)blockIdx.x >= ntiles) {
       bias_update_tile(p, lds, (int)blockIdx.x - ntiles);
     } else {
@@ -889,6 +909,31 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
     gemm_tile<BM, BN, BK, WK, A_KMAJOR, B_KMAJOR, EPI, VEC>(p, lds, blockIdx.x, gridDim.x);
   }
 }
+
+#ifdef KHG_DEFINE_UPDATE_GROUP
+// Up to kMaxGroup weight updates in one launch (GemmGroup above).  Measured on the eight updates of a
+// Switchboard-sized step (tools/group_probe.py, tools/group_stamps.py): 235 us against 262 us launched one by
+// one.  In the long grid the workgroups of a compute unit drift out of phase by themselves (lifetimes 11-17 us),
+// a start delay for half of the first round changed nothing beyond noise, and persistent workgroups looping
+// over tiles (no re-dispatch) measured the same as one workgroup per tile.
+__global__ __launch_bounds__(256) void gemm_update_group_kernel(GemmGroup g) {
+  __shared__ __attribute__((aligned(16))) float lds[gemm_lds_floats<64, 64, kBK, 1, false, false>()];
+  const int b = blockIdx.x;
+  int idx = 0;
+#pragma unroll
+  for (int i = 1; i < kMaxGroup; ++i)
+    if (i < g.n && b >= g.first[i]) idx = i;
+  const GemmParams &p = g.p[idx];
+  const int bid = b - g.first[idx];
+  const int ntiles = p.tiles_m * p.tiles_n * p.splitk;
+  if (bid >= ntiles) return;
+  update_tile64<64, 64, kBK, 1, false, false, EPI_UPDATE, true>(p, lds, bid, ntiles);
+}
+
+void launch_update_group(hipStream_t st, const GemmGroup &g) {
+  hipLaunchKernelGGL(gemm_update_group_kernel, dim3(g.first[g.n]), dim3(256), 0, st, g);
+}
+#endif  // KHG_DEFINE_UPDATE_GROUP
 
 // ---- sum of split-K slabs + the element-wise step that follows the GEMM ------------------------
 template <int EPI, int VEC>

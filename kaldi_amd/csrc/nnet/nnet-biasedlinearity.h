@@ -95,6 +95,39 @@ class BiasedLinearity : public UpdatableComponent {
     UpdateBias(err);
   }
 
+  /// The same step as Update(), written down as one item of hipF_affine_update_group instead of launched, so
+  /// that a training step can run the updates of all its layers in one launch behind the back-propagation
+  /// pass.  False (nothing written) when this layer's update is not the single fused launch (L1 penalty,
+  /// second weight buffer); after the grouped launch has been queued the caller calls AfterGroupedUpdate().
+  bool DescribeUpdate(const CuMatrix<BaseFloat> &input, const CuMatrix<BaseFloat> &err, khAffineUpdate *item) {
+    if (l1_penalty_ != 0.0 || double_buffer_) return false;
+    const int32 n = input.NumRows();
+    KALDI_ASSERT(err.NumRows() == n && err.NumCols() == output_dim_ && input.NumCols() == input_dim_);
+    item->N = n;
+    item->O = output_dim_;
+    item->I = input_dim_;
+    item->e = err.Data();
+    item->lde = err.Stride();
+    item->in = input.Data();
+    item->ldin = input.Stride();
+    item->gscale = average_grad_ ? 1.0 / n : 1.0;
+    item->momentum = momentum_;
+    item->lr = learn_rate_;
+    item->l2 = (l2_penalty_ != 0.0) ? learn_rate_ * l2_penalty_ * n : 0.0;
+    item->W_in = linearity_.Data();
+    item->ldw_in = linearity_.Stride();
+    item->W_out = linearity_.Data();
+    item->ldw_out = linearity_.Stride();
+    item->corr = KeepCorr() ? linearity_corr_.Data() : NULL;
+    item->ldcorr = linearity_corr_.Stride();
+    item->bias = bias_.Data();
+    item->bcorr = KeepCorr() ? bias_corr_.Data() : NULL;
+    return true;
+  }
+  void AfterGroupedUpdate() {
+    if (l2_upper_bound_ > 0.0) linearity_.ApplyRowL2UpperBound(l2_upper_bound_);
+  }
+
   /// True when the two halves below are independent: the weight half then reads only `input`,
   /// `err` and the old weights, the bias half only `err`, and they may be queued on different
   /// streams.  (With an L1 penalty the reference's pass order is kept and everything happens in

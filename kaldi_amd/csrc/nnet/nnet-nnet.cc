@@ -189,8 +189,24 @@ void Nnet::Backpropagate(const CuMatrix<BaseFloat> &in_err, CuMatrix<BaseFloat> 
     bl->SetDoubleBuffer(dp_ranks_ == 1 || dp_gather_);
     if (bl->UpdateKeepsOldWeights() || dp_ranks_ > 1) dev.Order(dev.MainStream(), dev.SideStream(), &layer_events_[i]);
   };
+  // Single GPU: the updates of the <biasedlinearity> layers are written down here and launched together behind
+  // the back-propagation pass (hipF_affine_update_group).  Same result as the reference's order: a layer's
+  // update reads its input, its output error and its own weights, all of which stay as they are until then, and
+  // no back-propagation below reads what it writes.
+  deferred_updates_.clear();
+  deferred_layers_.clear();
   auto update = [&](int32 i, const CuMatrix<BaseFloat> &input, const CuMatrix<BaseFloat> &err) {
     if (!overlap || !nnet_[i]->IsUpdatable()) {
+      if (dp_ranks_ == 1 && group_updates_ && nnet_[i]->IsUpdatable() && nnet_[i]->GetType() == Component::kBiasedLinearity &&
+          !dev.Profiling()) {
+        BiasedLinearity *bl = static_cast<BiasedLinearity *>(nnet_[i]);
+        khAffineUpdate item;
+        if (bl->GetLearnRate() > 0.0 && bl->DescribeUpdate(input, err, &item)) {
+          deferred_updates_.push_back(item);
+          deferred_layers_.push_back(i);
+          return;
+        }
+      }
       UpdateLayer(i, input, err);
       return;
     }
@@ -338,6 +354,12 @@ void Nnet::Backpropagate(const CuMatrix<BaseFloat> &in_err, CuMatrix<BaseFloat> 
     update(i, propagate_buf_[i], *err);
     err = below;
     --i;
+  }
+  if (!deferred_updates_.empty()) {
+    CuProfileScope p("BiasedLinearity::Update");
+    CU_SAFE_CALL(hipF_affine_update_group(dev.Stream(), static_cast<int32>(deferred_updates_.size()), &deferred_updates_[0]));
+    for (size_t k = 0; k < deferred_layers_.size(); ++k)
+      static_cast<BiasedLinearity *>(nnet_[deferred_layers_[k]])->AfterGroupedUpdate();
   }
   if (side_used) dev.Order(dev.SideStream(), dev.MainStream(), &join_event_);
   if (aux_used) dev.Order(dev.AuxStream(), dev.MainStream(), &aux_join_event_);

@@ -22,6 +22,8 @@
 #include "nnet/nnet-component.h"
 #include "util/kaldi-io.h"
 
+#include <cstdlib>
+
 namespace kaldi {
 
 class Xent;
@@ -78,6 +80,9 @@ class Nnet {
   /// Propagate keeps a window onto `in` instead of the reference's copy into its first buffer.
   /// The caller must then leave `in` alone until Backpropagate has returned.  Off by default.
   void SetBorrowInput(bool on) { borrow_input_ = on; }
+  /// Single GPU: launch the updates of all <biasedlinearity> layers together behind the back-propagation pass
+  /// instead of one by one between its steps (on by default; the results are the same, see Backpropagate).
+  void SetGroupUpdates(bool on) { group_updates_ = on; }
   /// Synchronous data-parallel training over `nranks` processes (one GPU each, communicator set up
   /// with hipK_comm_init): every <biasedlinearity> update becomes one exchange between the ranks and the
   /// same new weights on all of them, equal to one process training on the concatenated bunch.  The
@@ -109,6 +114,9 @@ class Nnet {
   std::vector<BaseFloat *> dp_layer_grad_;  // data-parallel: one gradient buffer per layer
   std::vector<size_t> dp_layer_grad_size_;
   khEvent_t join_event_, aux_join_event_;
+  bool group_updates_ = getenv("KALDI_AMD_NO_GROUP_UPDATES") == NULL;  // (the variable: for A/B measurements)
+  std::vector<khAffineUpdate> deferred_updates_;  // the updates of this Backpropagate call, launched at its end
+  std::vector<int32> deferred_layers_;
   KALDI_DISALLOW_COPY_AND_ASSIGN(Nnet);
 };
 

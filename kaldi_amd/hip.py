@@ -23,6 +23,15 @@ class MatrixDim(ctypes.Structure):
     _fields_ = [("rows", ctypes.c_int32), ("cols", ctypes.c_int32), ("stride", ctypes.c_int32)]
 
 
+class AffineUpdate(ctypes.Structure):
+    """khAffineUpdate: one item of hipF_affine_update_group (the arguments of hipF_affine_update_fused)."""
+    _fields_ = [("N", ctypes.c_int32), ("O", ctypes.c_int32), ("I", ctypes.c_int32),
+                ("e", ctypes.c_void_p), ("lde", ctypes.c_int32), ("in_", ctypes.c_void_p), ("ldin", ctypes.c_int32),
+                ("gscale", ctypes.c_float), ("momentum", ctypes.c_float), ("lr", ctypes.c_float), ("l2", ctypes.c_float),
+                ("W_in", ctypes.c_void_p), ("ldw_in", ctypes.c_int32), ("W_out", ctypes.c_void_p), ("ldw_out", ctypes.c_int32),
+                ("corr", ctypes.c_void_p), ("ldcorr", ctypes.c_int32), ("bias", ctypes.c_void_p), ("bcorr", ctypes.c_void_p)]
+
+
 _CTYPES = {
     "int": ctypes.c_int, "int32_t": ctypes.c_int32, "float": ctypes.c_float, "size_t": ctypes.c_size_t,
     "khStream_t": ctypes.c_void_p, "khEvent_t": ctypes.c_void_p, "MatrixDim": MatrixDim,

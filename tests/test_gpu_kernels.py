@@ -508,6 +508,52 @@ def test_affine_update_fused_equals_halves(hip, N, O_, I, mom):
             assert np.array_equal(Wb.numpy(), W)   # the old weights are only read
 
 
+@pytest.mark.parametrize("mom", [0.0, 0.9])
+def test_affine_update_group_equals_single_launches(hip, mom):
+    """hipF_affine_update_group (the updates of several layers in one launch) against one hipF_affine_update_fused
+    call per item: same bits in weights, bias and momentum buffers.  Eleven items, so the group is cut into two
+    launches; shapes with ragged edge tiles, a layer smaller than one tile, one whose rows are not 16-byte
+    aligned (launched on its own inside the call), and a second round on the updated weights.  count 0 is a no-op."""
+    import ctypes
+    h = hip
+    shapes = [(256, 2048, 1320), (256, 1483, 1024), (37, 50, 24), (300, 130, 72), (1, 65, 8), (256, 512, 2048),
+              (64, 200, 64), (256, 64, 64), (16, 17, 33), (256, 1024, 1024), (128, 700, 260)]
+    lr, l2 = 0.008, 1e-4
+    sets = []
+    for k, (N, O_, I) in enumerate(shapes):
+        x, e = rnd((N, I), 170 + k), rnd((N, O_), 190 + k, 0.01)
+        W, b = rnd((O_, I), 210 + k, 0.1), rnd((O_,), 230 + k, 0.5)
+        c0, bc0 = rnd((O_, I), 250 + k, 0.01), rnd((O_,), 270 + k, 0.01)
+        pitched = (N, O_, I) != (16, 17, 33)  # the odd one: dense rows of 33 floats
+        one = dict(N=N, O=O_, I=I, g=1.0 / N, x=h.DevMatrix.from_numpy(x, pitched), e=h.DevMatrix.from_numpy(e, pitched))
+        for tag in ("a", "b"):
+            one["W" + tag], one["b" + tag] = h.DevMatrix.from_numpy(W, pitched), dev(h, b, False)
+            one["c" + tag], one["bc" + tag] = h.DevMatrix.from_numpy(c0, pitched), dev(h, bc0, False)
+        sets.append(one)
+    h.call("hipF_affine_update_group", None, 0, None)
+    items = (h.AffineUpdate * len(sets))()
+    for k, s in enumerate(sets):
+        items[k] = h.AffineUpdate(s["N"], s["O"], s["I"], s["e"]._p.value, s["e"].stride, s["x"]._p.value, s["x"].stride, s["g"], mom,
+                                  lr, l2, s["Wb"]._p.value, s["Wb"].stride, s["Wb"]._p.value, s["Wb"].stride,
+                                  s["cb"]._p.value if mom else None, s["cb"].stride, s["bb"]._p.value,
+                                  s["bcb"]._p.value if mom else None)
+    for rnd_no in range(2):
+        for s in sets:
+            h.call("hipF_affine_update_fused", None, s["N"], s["O"], s["I"], s["e"].ptr, s["e"].stride, s["x"].ptr, s["x"].stride,
+                   f32(s["g"]), f32(mom), f32(lr), f32(l2), s["Wa"].ptr, s["Wa"].stride, s["Wa"].ptr, s["Wa"].stride,
+                   s["ca"].ptr if mom else None, s["ca"].stride, s["ba"].ptr, s["bca"].ptr if mom else None)
+        h.call("hipF_affine_update_group", None, len(sets), ctypes.cast(items, ctypes.c_void_p))
+        for k, s in enumerate(sets):
+            assert np.array_equal(s["Wa"].numpy(), s["Wb"].numpy()), (rnd_no, shapes[k])
+            assert np.array_equal(s["ba"].numpy(), s["bb"].numpy()), (rnd_no, shapes[k])
+            if mom:
+                assert np.array_equal(s["ca"].numpy(), s["cb"].numpy()) and np.array_equal(s["bca"].numpy(), s["bcb"].numpy())
+    # an item with a bad argument is refused
+    items[0].lde = 1
+    with pytest.raises(h.HipError):
+        h.call("hipF_affine_update_group", None, 1, ctypes.cast(items, ctypes.c_void_p))
+
+
 @pytest.mark.parametrize("N,O_,I", [(256, 1483, 1024), (256, 9000, 2048), (37, 50, 24), (64, 5000, 64), (64, 12000, 128)])
 def test_affine_forward_xent_equals_two_calls(hip, N, O_, I):
     """The fused output layer (GEMM + softmax + Xent::EvalVec) against hipF_affine_forward(softmax) followed by
