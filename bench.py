@@ -299,21 +299,25 @@ def main():
     value = world * done / elapsed
 
     # per kernel class: on one GPU the GEMM launches of a step come one after another in a fixed order --
-    # forward layer by layer, then top-down back-propagation / update pairs, the bottom layer's update last
+    # forward layer by layer, top-down back-propagation, then the updates of all layers as one grouped launch
+    # (with KALDI_AMD_NO_GROUP_UPDATES: back-propagation / update pairs, the bottom layer's update last)
     per_step = sp_n.value // roof_steps if roof_steps else 0
     classes = {}
     nl = len(dims) - 1
-    if kind == "train" and world == 1 and per_step == 3 * nl - 1 and sp_n.value == per_step * roof_steps:
+    FWD_OUT, FWD_HID = "forward (NT), output layer: split-K slabs for the softmax kernel", "forward (NT), hidden layer: bias + sigmoid epilogue"
+    BP, UPD = "back-propagation (NN): y(1-y) epilogue", "weight update (TN): SGD step in the epilogue, bias in the launch"
+    if kind == "train" and world == 1 and per_step in (2 * nl, 3 * nl - 1) and sp_n.value == per_step * roof_steps:
         for k in range(sp_n.value):
             pos = k % per_step
             if pos < nl:
-                name = "forward (NT), " + ("output layer: split-K slabs for the softmax kernel" if pos == nl - 1
-                                           else "hidden layer: bias + sigmoid epilogue")
+                name = FWD_OUT if pos == nl - 1 else FWD_HID
+            elif per_step == 2 * nl:
+                name = (UPD + ", all %d layers in one grouped launch" % nl if pos == per_step - 1
+                        else BP + (", output layer" if pos == nl else ", hidden layer"))
             else:
                 j = pos - nl
                 upd = (j % 2 == 1) or pos == per_step - 1
-                name = ("weight update (TN): SGD step in the epilogue, bias in the launch" if upd
-                        else "back-propagation (NN): y(1-y) epilogue") + (", output layer" if j < 2 else ", hidden layer")
+                name = (UPD if upd else BP) + (", output layer" if j < 2 else ", hidden layer")
             c = classes.setdefault(name, [0, 0.0, 0.0])
             c[0] += 1
             c[1] += sp_dur[k] * 1e3

@@ -614,10 +614,13 @@ KH_EXPORT int hipF_affine_update_fused(khStream_t s, int32_t N, int32_t O, int32
   return run_gemm<EPI_UPDATE>(s, false, false, p, /*allow_split=*/false);
 }
 
+bool group_big = getenv("KALDI_HIP_GROUP_TILE64") == nullptr;  // (the variable: for A/B measurements)
+
 KH_EXPORT int hipF_affine_update_group(khStream_t s, int32_t count, const khAffineUpdate *items) {
   KH_CHECK_INIT();
   KH_REQUIRE(count >= 0 && (count == 0 || items != nullptr));
   static const bool off = getenv("KALDI_HIP_NO_UPDATE_GROUP") != nullptr;  // for A/B measurements
+  const bool big = group_big;
   hipStream_t st = kh::pick(s);
   GemmGroup g;
   memset(&g, 0, sizeof(g));
@@ -626,7 +629,7 @@ KH_EXPORT int hipF_affine_update_group(khStream_t s, int32_t count, const khAffi
     if (g.n == 0) return KH_OK;
     {
       TimedLaunch tl(st, flops);
-      launch_update_group(st, g);
+      launch_update_group(st, g, big);
     }
     g.n = 0;
     g.first[0] = 0;
@@ -653,7 +656,7 @@ KH_EXPORT int hipF_affine_update_group(khStream_t s, int32_t count, const khAffi
     p.bcorr = u.bcorr;
     p.bias_tiles = (u.O + 63) / 64;
     const bool vec = kh::aligned16(p.A) && kh::aligned16(p.B) && (p.lda % 4 == 0) && (p.ldb % 4 == 0);
-    Plan plan = {0, 1, ((p.K + kBK - 1) / kBK) * kBK};  // 64 x 64 tiles, K whole
+    Plan plan = {big ? 3 : 0, 1, ((p.K + kBK - 1) / kBK) * kBK};  // 128 x 128 or 64 x 64 tiles, K whole
     apply_plan(p, plan, false, false);
     if (off || !vec || p.a_bytes == 0 || force_bm > 0) {
       // not for the grouped kernel: on its own, in order

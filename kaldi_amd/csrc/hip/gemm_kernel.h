@@ -8,6 +8,9 @@
 
 #include "common.h"
 
+#ifndef KH_UPDATE_STORE_AUX
+#define KH_UPDATE_STORE_AUX 16  // cache policy of the update epilogue's stores: 16 = sc1 (write-through)
+#endif
 #ifndef KH_SCHED
 #define KH_SCHED 3  // K-loop form: 0 group-by-group fragments, 2 whole-tile fragments, 3 whole-tile except in the update GEMMs
 #endif
@@ -71,7 +74,7 @@ struct GemmGroup {
   int first[kMaxGroup + 1];
   GemmParams p[kMaxGroup];
 };
-void launch_update_group(hipStream_t st, const GemmGroup &g);
+void launch_update_group(hipStream_t st, const GemmGroup &g, bool big);  // big: 128 x 128 tiles, else 64 x 64
 
 // launches the main kernel for tile configuration `cfg` (index into the planner's table) and operand layout
 template <int EPI>
@@ -98,9 +101,15 @@ void launch_reduce(hipStream_t st, const GemmParams &p, const float *slabs, int 
   do {                                                                                                    \
     if (p.stamps && threadIdx.x == 0) p.stamps[(size_t)blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memrealtime(); \
   } while (0)
+// cycle stamp into slot i (14, 15) of the workgroup's 16
+#define KH_CYC(i)                                                                                     \
+  do {                                                                                                \
+    if (p.stamps && threadIdx.x == 0) p.stamps[(size_t)blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
 #else
 #define KH_STAMP(i) do { } while (0)
 #define KH_RT(i) do { } while (0)
+#define KH_CYC(i) do { } while (0)
 #endif
 
 // The epilogue's second operand of one output element, fetched before any store so that the
@@ -170,11 +179,13 @@ constexpr int gemm_lds_floats() {
 
 // One output tile by one workgroup: tile `bid` of the `nblk` this product is cut into (`bid` must be
 // congruent to blockIdx.x modulo 8 for the XCD-aware decode below to keep its meaning).
-template <int BM, int BN, int BK, int WK, bool A_KMAJOR, bool B_KMAJOR, int EPI, bool VEC>
+// NW = 8 (only with WK = 1): a 512-thread workgroup, waves arranged 2 x 4 over the tile.
+template <int BM, int BN, int BK, int WK, bool A_KMAJOR, bool B_KMAJOR, int EPI, bool VEC, int NW = 4>
 __device__ __forceinline__ void gemm_tile(const GemmParams &p, float *lds, const int bid, const int nblk) {
-  constexpr int NT = 256;
-  constexpr int WAVES_M = (WK == 1) ? 2 : 1, WAVES_N = (WK == 4) ? 1 : 2;
-  static_assert(WAVES_M * WAVES_N * WK == 4, "4 waves per workgroup");
+  constexpr int NT = 64 * NW;
+  static_assert(NW == 4 || (NW == 8 && WK == 1), "4 waves, or 8 waves without a K split over waves");
+  constexpr int WAVES_M = (WK == 1) ? 2 : 1, WAVES_N = (NW == 8) ? 4 : (WK == 4) ? 1 : 2;
+  static_assert(WAVES_M * WAVES_N * WK == NW, "waves per workgroup");
   constexpr int BKT = BK * WK;                          // K depth of one staged tile
   constexpr int TM = BM / (WAVES_M * 32), TN = BN / (WAVES_N * 32);
   static_assert(TM >= 1 && TN >= 1, "tile too small for this wave arrangement");
@@ -676,17 +687,22 @@ __device__ __forceinline__ void gemm_tile(const GemmParams &p, float *lds, const
       // are not read again before the next forward pass, and 17 MB of dirty lines in L2 would otherwise be written
       // back at the kernel's end, where the next launch waits for them (3-4 us per update launch measured).
       // Same arithmetic, element for element, as epi_store<EPI_UPDATE>.
-      static_assert(!PREFETCH || 4 * 32 * 36 <= 2 * (A_ELEMS + B_ELEMS), "transposition areas larger than the tile buffers");
+      static_assert(!PREFETCH || NW * 32 * 36 <= 2 * (A_ELEMS + B_ELEMS), "transposition areas larger than the tile buffers");
       typedef int v4i_t __attribute__((ext_vector_type(4)));
       const __amdgpu_buffer_rsrc_t rsrc_wout = __builtin_amdgcn_make_buffer_rsrc((void *)p.Wout, 0, p.wout_bytes, 0x00020000);
       const __amdgpu_buffer_rsrc_t rsrc_c = __builtin_amdgcn_make_buffer_rsrc((void *)p.C, 0, p.c_bytes, 0x00020000);
       float *xp = lds + wid * (32 * 36);
       lds_barrier();  // every wave has read its last operand fragments
+      KH_CYC(14);
 #pragma unroll
       for (int a = 0; a < TM * TN; ++a) {
         if (a >= npre) prefetch_acc(a);  // (K shorter than the number of accumulators)
 #pragma unroll
         for (int r = 0; r < 16; ++r) xp[((r & 3) + 8 * (r >> 2) + 4 * lh) * 36 + li] = acc[a / TN][a % TN][r];
+        if (a == 0) {
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          KH_CYC(15);
+        }
         const int col = n0 + wn0 + (a % TN) * 32 + (lane & 7) * 4;
 #pragma unroll
         for (int pass = 0; pass < 4; ++pass) {
@@ -706,10 +722,10 @@ __device__ __forceinline__ void gemm_tile(const GemmParams &p, float *lds, const
           if (col < p.N) {  // (rows past the matrix are dropped by the buffer bounds)
             if (p.C) {
               const v4i_t cv = {__float_as_int(c[0]), __float_as_int(c[1]), __float_as_int(c[2]), __float_as_int(c[3])};
-              __builtin_amdgcn_raw_buffer_store_b128(cv, rsrc_c, vec_off(a, pass, p.ldc), 0, 16);
+              __builtin_amdgcn_raw_buffer_store_b128(cv, rsrc_c, vec_off(a, pass, p.ldc), 0, KH_UPDATE_STORE_AUX);
             }
             const v4i_t wv4 = {__float_as_int(w[0]), __float_as_int(w[1]), __float_as_int(w[2]), __float_as_int(w[3])};
-            __builtin_amdgcn_raw_buffer_store_b128(wv4, rsrc_wout, vec_off(a, pass, p.ldwout), 0, 16);
+            __builtin_amdgcn_raw_buffer_store_b128(wv4, rsrc_wout, vec_off(a, pass, p.ldwout), 0, KH_UPDATE_STORE_AUX);
           }
         }
       }
@@ -801,7 +817,9 @@ __device__ __forceinline__ void gemm_tile(const GemmParams &p, float *lds, const
 __device__ __forceinline__ void bias_update_tile(const GemmParams &p, float *lds, int tile) {
   KH_RT(10);
   const int tid = threadIdx.x;
-  if (p.a_bytes != 0 && (p.lda & 3) == 0 && (reinterpret_cast<size_t>(p.A) & 15) == 0) {
+  if (tid >= 256) {
+    // (a 512-thread workgroup: the second half only keeps the barrier company)
+  } else if (p.a_bytes != 0 && (p.lda & 3) == 0 && (reinterpret_cast<size_t>(p.A) & 15) == 0) {
     // Thread (g = tid / 16, quad = tid % 16) sums rows g, g + 16, g + 32, ... of 4 adjacent columns: one 16-byte
     // buffer load per row, the 16 rows of a 256-frame bunch all in flight, added in row order.  Rows past K lie
     // beyond the descriptor's range and load as 0; columns past M are summed (from padding or the next row)
@@ -864,31 +882,35 @@ __device__ __forceinline__ void bias_update_tile(const GemmParams &p, float *lds
   KH_RT(13);
 }
 
-// One 64-row tile of a weight update, and the bias half of the update where this workgroup carries it.
-// The bias half rides in the update's launch.  With 64-row tiles, one workgroup of every tile row
-// takes the column sums of the error for its 64 outputs first (the columns it is about to stream as its A
-// operand) and then goes on to its tile: it runs that much behind the workgroups it shares the compute unit
-// with and catches up when they are done, so the launch ends barely later than without the sums.  (Tried
-// and measured: workgroups of their own in front of the tiles held 32 of the 1024 workgroup slots that the
-// tiles of a 2048 x 2048 layer fill exactly, and the 32 tiles left over started most of a workgroup lifetime
-// late; at the end of the grid they start when the first tiles finish and add their whole 3.7 us -- kernel
-// arguments, one round of loads, the exchange, the bias round trip -- to the launch.)  The chosen column
-// walks with the row so that the carriers spread over the XCDs.
-template <int BM, int BN, int BK, int WK, bool A_KMAJOR, bool B_KMAJOR, int EPI, bool VEC>
-__device__ __forceinline__ void update_tile64(const GemmParams &p, float *lds, const int bid, const int ntiles) {
-  static_assert(BM == 64, "64-row tiles");
+// One tile (64 or 128 rows) of a weight update, and the bias half of the update where this workgroup carries it.
+// The bias half rides in the update's launch: one workgroup of every tile row takes the column sums of the
+// error for its outputs first (the columns it is about to stream as its A operand), 64 at a time, and then
+// goes on to its tile: it runs that much behind the workgroups it shares the compute unit with and catches up
+// when they are done, so the launch ends barely later than without the sums.  (Tried and measured: workgroups
+// of their own in front of the tiles held 32 of the 1024 workgroup slots that the 64 x 64 tiles of a
+// 2048 x 2048 layer fill exactly, and the 32 tiles left over started most of a workgroup lifetime late; at the
+// end of the grid they start when the first tiles finish and add their whole 3.7 us -- kernel arguments, one
+// round of loads, the exchange, the bias round trip -- to the launch.)  The chosen column walks with the row
+// so that the carriers spread over the XCDs.
+template <int BM, int BN, int BK, int WK, bool A_KMAJOR, bool B_KMAJOR, int EPI, bool VEC, int NW = 4>
+__device__ __forceinline__ void update_tile(const GemmParams &p, float *lds, const int bid, const int ntiles) {
+  static_assert(BM % 64 == 0, "tile rows in units of the 64 outputs of a bias tile");
   if (p.bias_tiles > 0) {
     int L = bid;  // same decode as gemm_tile
     if ((ntiles & 7) == 0) L = (L & 7) * (ntiles >> 3) + (L >> 3);
     const int mi = L % p.tiles_m;
     L /= p.tiles_m;
     const int ks = L % p.splitk, ni = L / p.splitk;
-    if (ks == 0 && ni == ((p.tiles_n >= 8) ? (mi & 7) * (p.tiles_n >> 3) : 0) && mi < p.bias_tiles) {
-      bias_update_tile(p, lds, mi);
-      __syncthreads();
+    if (ks == 0 && ni == ((p.tiles_n >= 8) ? (mi & 7) * (p.tiles_n >> 3) : 0)) {
+#pragma unroll
+      for (int h = 0; h < BM / 64; ++h)
+        if (mi * (BM / 64) + h < p.bias_tiles) {
+          bias_update_tile(p, lds, mi * (BM / 64) + h);
+          __syncthreads();
+        }
     }
   }
-  gemm_tile<BM, BN, BK, WK, A_KMAJOR, B_KMAJOR, EPI, VEC>(p, lds, bid, ntiles);
+  gemm_tile<BM, BN, BK, WK, A_KMAJOR, B_KMAJOR, EPI, VEC, NW>(p, lds, bid, ntiles);
 }
 
 template <int BM, int BN, int BK, int WK, bool A_KMAJOR, bool B_KMAJOR, int EPI, bool VEC>
@@ -896,10 +918,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
   __shared__ __attribute__((aligned(16))) float lds[gemm_lds_floats<BM, BN, BK, WK, A_KMAJOR, B_KMAJOR>()];
   if constexpr (EPI == EPI_UPDATE) {
     static_assert(gemm_lds_floats<BM, BN, BK, WK, A_KMAJOR, B_KMAJOR>() >= 16 * 64, "bias tile needs 1024 floats");
-    // 64-row tiles: the bias half inside tile workgroups (update_tile64); other tile heights: workgroups at the end
+    // 64-row tiles: the bias half inside tile workgroups (update_tile); other tile heights: workgroups at the end
     const int ntiles = p.tiles_m * p.tiles_n * p.splitk;
     if constexpr (BM == 64) {
-      update_tile64<BM, BN, BK, WK, A_KMAJOR, B_KMAJOR, EPI, VEC>(p, lds, blockIdx.x, ntiles);
+      update_tile<BM, BN, BK, WK, A_KMAJOR, B_KMAJOR, EPI, VEC>(p, lds, blockIdx.x, ntiles);
     } else if ((int)blockIdx.x >= ntiles) {
       bias_update_tile(p, lds, (int)blockIdx.x - ntiles);
     } else {
@@ -912,12 +934,19 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
 
 #ifdef KHG_DEFINE_UPDATE_GROUP
 // Up to kMaxGroup weight updates in one launch (GemmGroup above).  Measured on the eight updates of a
-// Switchboard-sized step (tools/group_probe.py, tools/group_stamps.py): 235 us against 262 us launched one by
-// one.  In the long grid the workgroups of a compute unit drift out of phase by themselves (lifetimes 11-17 us),
-// a start delay for half of the first round changed nothing beyond noise, and persistent workgroups looping
-// over tiles (no re-dispatch) measured the same as one workgroup per tile.
-__global__ __launch_bounds__(256) void gemm_update_group_kernel(GemmGroup g) {
-  __shared__ __attribute__((aligned(16))) float lds[gemm_lds_floats<64, 64, kBK, 1, false, false>()];
+// Switchboard-sized step (tools/group_probe.py, tools/group_stamps.py): with 64 x 64 tiles 235 us against 262 us
+// launched one by one.  In the long grid the workgroups of a compute unit drift out of phase by themselves
+// (lifetimes 11-17 us), a start delay for half of the first round changed nothing beyond noise, and persistent
+// workgroups looping over tiles (no re-dispatch) measured the same as one workgroup per tile.
+// What bounds the 64 x 64 tile there is the compute unit's vector memory path, not the matrix cores: at K = 256 a
+// tile loads 128 KB of operands (+ 16 KB of old weights, 16 KB stored) for 2.1 MFLOP, ~19 bytes per cycle and
+// compute unit at the measured rate, and the four store instructions of a wave's epilogue took 4000 cycles to
+// issue behind that traffic.  BIG: 128 x 128 tiles by 512-thread workgroups (8 waves of 64 x 32, two workgroups
+// per compute unit = the same 4 waves per SIMD): half the operand bytes per FLOP.
+template <bool BIG>
+__global__ __launch_bounds__(BIG ? 512 : 256) __attribute__((amdgpu_waves_per_eu(4, 4))) void gemm_update_group_kernel(GemmGroup g) {
+  constexpr int BT = BIG ? 128 : 64;
+  __shared__ __attribute__((aligned(16))) float lds[gemm_lds_floats<BT, BT, kBK, 1, false, false>()];
   const int b = blockIdx.x;
   int idx = 0;
 #pragma unroll
@@ -927,11 +956,12 @@ __global__ __launch_bounds__(256) void gemm_update_group_kernel(GemmGroup g) {
   const int bid = b - g.first[idx];
   const int ntiles = p.tiles_m * p.tiles_n * p.splitk;
   if (bid >= ntiles) return;
-  update_tile64<64, 64, kBK, 1, false, false, EPI_UPDATE, true>(p, lds, bid, ntiles);
+  update_tile<BT, BT, kBK, 1, false, false, EPI_UPDATE, true, BIG ? 8 : 4>(p, lds, bid, ntiles);
 }
 
-void launch_update_group(hipStream_t st, const GemmGroup &g) {
-  hipLaunchKernelGGL(gemm_update_group_kernel, dim3(g.first[g.n]), dim3(256), 0, st, g);
+void launch_update_group(hipStream_t st, const GemmGroup &g, bool big) {
+  if (big) hipLaunchKernelGGL(gemm_update_group_kernel<true>, dim3(g.first[g.n]), dim3(512), 0, st, g);
+  else hipLaunchKernelGGL(gemm_update_group_kernel<false>, dim3(g.first[g.n]), dim3(256), 0, st, g);
 }
 #endif  // KHG_DEFINE_UPDATE_GROUP
 

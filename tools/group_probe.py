@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """The eight weight updates of a Switchboard-sized step (bunch 256) launched one by one
-(hipF_affine_update_fused) and as one grouped launch (hipF_affine_update_group) under several
-de-phasing settings: microseconds per set, and a bit-for-bit comparison of the results.
+(hipF_affine_update_fused) and as one grouped launch (hipF_affine_update_group): microseconds per
+set, and a bit-for-bit comparison of the results.
 Weights cycle through two copies of the net (370 MB: not cache-resident, as in a training step)."""
 import ctypes
 import os
@@ -89,20 +89,8 @@ for i in range(300):  # clock ramp
 flops = sum(2.0 * N * L["O"] * L["I"] for L in layers)
 ideal = flops / 157.3e6
 print("MFMA time of the set at peak: %.1f us" % ideal)
-for rnd in range(2):
-    for grid in (0, 1024, 768, 512, 1280):
-        h.call("hipK_gemm_group_grid", grid)
-        for ticks in (0, 500, 800):
-            h.call("hipK_gemm_group_delay", ticks, 1024, 256)
-            t = bench(grouped)
-            print("grouped, grid %4d, delay %4d ticks: %.1f us (%.0f%%)" % (grid, ticks, t, 100 * ideal / t), flush=True)
-    h.call("hipK_gemm_group_grid", 0)
+for rnd in range(3):
     t = bench(one_by_one)
     print("one by one: %.1f us (%.0f%%)" % (t, 100 * ideal / t), flush=True)
-    for ticks, blocks, stride in ((0, 1024, 256), (300, 1024, 256), (500, 1024, 256), (700, 1024, 256), (900, 1024, 256),
-                                  (1100, 1024, 256), (700, 1024, 128), (700, 1024, 512), (700, 1024, 8), (700, 1024, 1),
-                                  (700, 2048, 256), (500, 1024, 1), (900, 1024, 1)):
-        h.call("hipK_gemm_group_delay", ticks, blocks, stride)
-        t = bench(grouped)
-        print("grouped, delay %4d ticks, first round %d blocks, runs of %3d: %.1f us (%.0f%%)" % (ticks, blocks, stride, t, 100 * ideal / t),
-              flush=True)
+    t = bench(grouped)
+    print("grouped:    %.1f us (%.0f%%)" % (t, 100 * ideal / t), flush=True)

@@ -1,6 +1,6 @@
 """Diagnostic: in-kernel stamps of one grouped weight-update launch (hipF_affine_update_group, one workgroup per
 tile) taken after a long run of back-to-back launches (clock settled).  Needs the stamps build:
-usage: KALDI_AMD_HIP_LIB=tools/dbg/libkaldi_hip.so python tools/group_stamps.py [delay_ticks]"""
+usage: KALDI_AMD_HIP_LIB=tools/dbg/libkaldi_hip.so python tools/group_stamps.py"""
 import ctypes
 import os
 import sys
@@ -28,9 +28,7 @@ for k, li in enumerate(order):
     L = layers[li]
     arr[k] = h.AffineUpdate(N, L["O"], L["I"], L["e"]._p.value, L["e"].stride, L["x"]._p.value, L["x"].stride, 1.0, 0.0, 1e-6, 0.0,
                             L["W"]._p.value, L["W"].stride, L["W"]._p.value, L["W"].stride, None, 0, L["b"]._p.value, None)
-    nblk += ((L["O"] + 63) // 64 * ((L["I"] + 63) // 64) + 7) & ~7
-h.call("hipK_gemm_group_grid", 0)
-h.call("hipK_gemm_group_delay", int(sys.argv[1]) if len(sys.argv) > 1 else 0, 1024, 256)
+    nblk += ((L["O"] + 63) // 64 * ((L["I"] + 63) // 64) + 7) & ~7  # (upper bound for either tile size)
 for _ in range(300):
     h.call("hipF_affine_update_group", None, len(order), ctypes.cast(arr, ctypes.c_void_p))
 buf = np.zeros(nblk * 16, np.uint64)
@@ -50,6 +48,12 @@ d = np.diff(full[:, :8], axis=1)
 print("per-workgroup phase lengths, cycles (p10 / median / p90):")
 for i in range(7):
     print("  %-14s -> %-14s %8d %8d %8d" % (names[i], names[i + 1], np.percentile(d[:, i], 10), np.median(d[:, i]), np.percentile(d[:, i], 90)))
+ok = (full[:, 14] > 0) & (full[:, 15] > 0)
+if ok.any():
+    a, b2, c = full[ok, 14] - full[ok, 5], full[ok, 15] - full[ok, 14], full[ok, 6] - full[ok, 15]
+    print("epilogue of wave 0, cycles (p10 / median / p90): barrier after the K loop %d %d %d; accumulators into LDS %d %d %d; "
+          "LDS reads, arithmetic, store issue %d %d %d" % (np.percentile(a, 10), np.median(a), np.percentile(a, 90), np.percentile(b2, 10),
+                                                          np.median(b2), np.percentile(b2, 90), np.percentile(c, 10), np.median(c), np.percentile(c, 90)))
 # how many workgroups are resident over time, and how many of them are inside their K loop
 t0 = rt0.min()
 edges = np.arange(0, (rt1.max() - t0) / 100.0 + 2.0, 2.0)
