@@ -658,6 +658,9 @@ KH_EXPORT int hipF_affine_update_group(khStream_t s, int32_t count, const khAffi
     const bool vec = kh::aligned16(p.A) && kh::aligned16(p.B) && (p.lda % 4 == 0) && (p.ldb % 4 == 0);
     Plan plan = {big ? 3 : 0, 1, ((p.K + kBK - 1) / kBK) * kBK};  // 128 x 128 or 64 x 64 tiles, K whole
     apply_plan(p, plan, false, false);
+    // an XCD's run of tiles: leave the operand with more tiles sliced (the 9000-output layer: the error matrix)
+    static const bool rows_first = getenv("KALDI_HIP_GROUP_ROWS_FIRST") != nullptr;  // for A/B measurements
+    p.n_fastest = (!rows_first && p.tiles_m > 2 * p.tiles_n) ? 1 : 0;
     if (off || !vec || p.a_bytes == 0 || force_bm > 0) {
       // not for the grouped kernel: on its own, in order
       int rc = flush();

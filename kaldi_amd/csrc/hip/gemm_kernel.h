@@ -35,6 +35,7 @@ struct GemmParams {
   int splitk, k_per_split;
   int a_bytes, b_bytes;  // operand footprints when both are below 2 GiB (buffer addressing), else 0
   int tiles_m, tiles_n;
+  int n_fastest;  // tile order inside an XCD's run of tiles: 0 = down the rows first, 1 = along the columns first
   float alpha, beta;
   float *C;
   int ldc;
@@ -207,12 +208,22 @@ __device__ __forceinline__ void gemm_tile(const GemmParams &p, float *lds, const
 #ifndef KH_NO_CHAIN_PRIO
   if (EPI != EPI_UPDATE && EPI != EPI_RBM) __builtin_amdgcn_s_setprio(3);
 #endif
+  // Which way the run walks decides which operand an XCD reads whole: down the rows first it covers every row
+  // tile of a few column tiles (all of A, a slice of B); along the columns first the other way round -- the host
+  // picks the order that leaves the larger operand sliced (n_fastest; only without a K split).
   int L = bid;
   if ((nblk & 7) == 0) L = (L & 7) * (nblk >> 3) + (L >> 3);
-  const int mi = L % p.tiles_m;
-  L /= p.tiles_m;
-  const int ks = L % p.splitk;
-  const int ni = L / p.splitk;
+  int mi, ni, ks;
+  if (p.n_fastest) {
+    ni = L % p.tiles_n;
+    mi = L / p.tiles_n;
+    ks = 0;
+  } else {
+    mi = L % p.tiles_m;
+    L /= p.tiles_m;
+    ks = L % p.splitk;
+    ni = L / p.splitk;
+  }
   const int m0 = mi * BM, n0 = ni * BN;
   const int kbeg = ks * p.k_per_split;
   const int kend = min(p.K, kbeg + p.k_per_split);
@@ -898,9 +909,17 @@ __device__ __forceinline__ void update_tile(const GemmParams &p, float *lds, con
   if (p.bias_tiles > 0) {
     int L = bid;  // same decode as gemm_tile
     if ((ntiles & 7) == 0) L = (L & 7) * (ntiles >> 3) + (L >> 3);
-    const int mi = L % p.tiles_m;
-    L /= p.tiles_m;
-    const int ks = L % p.splitk, ni = L / p.splitk;
+    int mi, ni, ks;
+    if (p.n_fastest) {
+      ni = L % p.tiles_n;
+      mi = L / p.tiles_n;
+      ks = 0;
+    } else {
+      mi = L % p.tiles_m;
+      L /= p.tiles_m;
+      ks = L % p.splitk;
+      ni = L / p.splitk;
+    }
     if (ks == 0 && ni == ((p.tiles_n >= 8) ? (mi & 7) * (p.tiles_n >> 3) : 0)) {
 #pragma unroll
       for (int h = 0; h < BM / 64; ++h)

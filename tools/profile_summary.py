@@ -32,21 +32,18 @@ if f:
         lines.append("| `%s` | %s | %.3f | %.2f | %.2f | %.2f | %.1f |" % (
             short(r["Name"]), r["Calls"], float(r["TotalDurationNs"]) / 1e6, float(r["AverageNs"]) / 1e3,
             float(r["MinNs"]) / 1e3, float(r["MaxNs"]) / 1e3, 100 * float(r["TotalDurationNs"]) / tot))
-    g = [r for r in rows if "gemm_kernel" in r["Name"]]
+    g = [r for r in rows if "gemm_" in r["Name"]]
     gc, gt = sum(int(r["Calls"]) for r in g), sum(float(r["TotalDurationNs"]) for r in g)
-    lines += ["", "all `gemm_kernel` instantiations: %d launches, %.3f ms, average %.2f us per launch" % (gc, gt / 1e6, gt / gc / 1e3 if gc else 0), ""]
+    lines += ["", "all GEMM kernels (`gemm_kernel` instantiations, `gemm_update_group_kernel`): %d launches, %.3f ms, average %.2f us per launch" % (gc, gt / 1e6, gt / gc / 1e3 if gc else 0), ""]
 
 
 def pmc(sub):
     f = one("/%s/**/*counter_collection.csv" % sub)
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
-    grid = {}
     if f:
         for r in csv.DictReader(open(f)):
-            k = short(r["Kernel_Name"])
-            agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
-            grid[k] = int(r["Grid_Size"]) // 64
-    return agg, grid
+            agg[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return agg, None
 
 
 fa, _ = pmc("fetch")
@@ -62,27 +59,35 @@ if fa or wa:
         rd = 2 * 1024 * sum(fr) / max(len(fr), 1) / 1e6
         wt = 1024 * sum(wr) / max(len(wr), 1) / 1e6
         lines.append("| `%s` | %d | %.2f | %.2f |" % (k, max(len(fr), len(wr)), rd, wt))
-        if "gemm_kernel" in k:
+        if "gemm_" in k:
             tr += 2 * 1024 * sum(fr)
             tw += 1024 * sum(wr) * (len(fr) / max(len(wr), 1))
             n += len(fr)
     if n:
-        lines += ["", "all `gemm_kernel` launches: %.2f MB read + %.2f MB written = %.2f MB per launch on average" %
+        lines += ["", "all GEMM launches: %.2f MB read + %.2f MB written = %.2f MB per launch on average" %
                   (tr / n / 1e6, tw / n / 1e6, (tr + tw) / n / 1e6), "", "GEMM_TRAFFIC_BYTES_PER_LAUNCH=%d" % ((tr + tw) / n), ""]
-sa, grid = pmc("sq")
-if sa:
-    lines += ["### SQ counters of the GEMM kernels (per wave, cycles; one `--pmc` pass; kernels serialised by the profiler)", "",
-              "| kernel | waves | wave cycles | MFMA busy | busy % | parked (s_waitcnt/barrier) | issue-stall | LDS issue-stall |",
-              "|---|---:|---:|---:|---:|---:|---:|---:|"]
-    for k in sorted(sa):
-        if "gemm_kernel" not in k:
-            continue
-        m = {c: sum(v) / len(v) for c, v in sa[k].items()}
-        w = grid[k]
-        wc = 4 * m["SQ_WAVE_CYCLES"] / w
-        mb = m["SQ_VALU_MFMA_BUSY_CYCLES"] / w
-        lines.append("| `%s` | %d | %.0f | %.0f | %.1f | %.0f | %.0f | %.0f |" % (
-            k, w, wc, mb, 100 * mb / wc, 4 * m["SQ_WAIT_ANY"] / w, 4 * m["SQ_WAIT_INST_ANY"] / w, 4 * m["SQ_WAIT_INST_LDS"] / w))
+# SQ pass: one row per (kernel, grid size) -- the same instantiation serves layers of different sizes
+f = one("/sq/**/*counter_collection.csv")
+if f:
+    sq = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open(f)):
+        k = short(r["Kernel_Name"])
+        if "gemm" in k:
+            sq[(k, int(r["Grid_Size"]) // 64)][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    lines += ["### SQ counters of the GEMM kernels, per launch shape (one `--pmc` pass; kernels serialised by the profiler)", "",
+              "MFMA pipe busy = `SQ_VALU_MFMA_BUSY_CYCLES` (busy cycles summed over all SIMDs; 64 per `v_mfma_f32_32x32x2_f32`) / "
+              "(1024 SIMDs x the launch's length, taken as `SQ_BUSY_CYCLES` / 32 shader engines): the share of the chip's matrix-core "
+              "cycles this launch used.  The per-wave columns are averages over the launch's waves, in cycles (`SQ_*` x 4); a wave "
+              "that shares its SIMD with n - 1 others can be MFMA-busy 1/n of its own lifetime at most.", "",
+              "| kernel | waves | launches | launch cycles | MFMA pipe busy % | wave lifetime | wave's own MFMA | parked (s_waitcnt/barrier) | issue-stall | LDS issue-stall |",
+              "|---|---:|---:|---:|---:|---:|---:|---:|---:|---:|"]
+    for (k, w) in sorted(sq):
+        m = {c: sum(v) / len(v) for c, v in sq[(k, w)].items()}
+        n = len(sq[(k, w)]["SQ_WAVE_CYCLES"])
+        launch = m["SQ_BUSY_CYCLES"] / 32.0
+        lines.append("| `%s` | %d | %d | %.0f | %.1f | %.0f | %.0f | %.0f | %.0f | %.0f |" % (
+            k, w, n, launch, 100.0 * m["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * launch), 4 * m["SQ_WAVE_CYCLES"] / w,
+            m["SQ_VALU_MFMA_BUSY_CYCLES"] / w, 4 * m["SQ_WAIT_ANY"] / w, 4 * m["SQ_WAIT_INST_ANY"] / w, 4 * m["SQ_WAIT_INST_LDS"] / w))
     lines.append("")
 bench = [l for l in open(d + "/kt.log") if l.startswith("{")]
 if bench:
