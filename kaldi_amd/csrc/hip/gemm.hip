@@ -68,10 +68,11 @@ struct Plan {
 // in-kernel stamps) hides behind the K loops of the workgroups that share the CU, so it is exposed
 // once per round of co-resident workgroups; a split K adds the slab round trip and the launch of
 // the kernel that sums the slabs.
+const bool old_staging_term = getenv("KALDI_HIP_PLAN_OLD_STAGING") != nullptr;  // for A/B measurements
 int force_bm = -1, force_bn = -1, force_s = -1;
 bool env_read = false;
 
-Plan make_plan(int M, int N, int K, int num_cu, bool allow_split, bool always_slabs, bool allow_wk) {
+Plan make_plan(int M, int N, int K, int num_cu, bool allow_split, bool always_slabs, bool allow_wk, bool kmajor_whole_tile) {
   static bool wk_on = true;
   if (!env_read) {
     env_read = true;
@@ -102,7 +103,11 @@ Plan make_plan(int M, int N, int K, int num_cu, bool allow_split, bool always_sl
       const double kper = (double)kt_per * bkt;
       const double mfma = (double)t.bm * t.bn * kper * 2.0 / 256.0 * 1.08;
       // (K split over waves: same MFMA count per byte staged as the 64x64 tile is charged below)
-      const double mem = t.wk > 1 ? mfma * (1.28 / 1.08) : (double)(t.bm + t.bn) * kper * 4.0 / 12.5;
+      // Both operands K-contiguous and whole-tile fragments (forward products): the 64x64 K loop measures 1090-1110
+      // cycles per 1024 of MFMA (in-kernel stamps), i.e. the MFMA term itself; the staging term below dates from
+      // the group-by-group loop and still describes the other layouts.  (Output layer of the Switchboard net,
+      // 256 x 9000 x 2048 + row kernel: 64x64 split 2 measures 92 us, the 32x64 split 2 the old term preferred 100.)
+      const double mem = t.wk > 1 ? mfma * (1.28 / 1.08) : kmajor_whole_tile ? 0.0 : (double)(t.bm + t.bn) * kper * 4.0 / 12.5;
       const double per_block = mfma > mem ? mfma : mem;
       const double n = ceil(blocks / num_cu);
       // with two or more workgroups on every CU one's stalls are filled by another's MFMAs
@@ -116,6 +121,10 @@ Plan make_plan(int M, int N, int K, int num_cu, bool allow_split, bool always_sl
       const double rounds = n / (co > 1.0 ? co : 1.0);
       double cost = (n * per_block * share + (rounds > 1.0 ? rounds : 1.0) * t.fixed) / cyc_per_us;
       if (s > 1 || always_slabs) cost += (s + 1.0) * (double)M * N * 4.0 / 3.5e6 + 2.5;
+      // every doubling of the split doubles the workgroups that pay a prologue and an epilogue, which the fixed
+      // term above undercounts for short K ranges (sweep of the 256 x 9000 x 2048 product: 64x64 split 4 measures
+      // 5.7 us more than split 2 where the terms above put it 0.2 us ahead)
+      for (int d = s; d > 1; d >>= 1) cost += 1.0;
       if (cost < best_cost) {
         best_cost = cost;
         best.cfg = c;
@@ -195,7 +204,8 @@ int run_gemm(khStream_t s, bool a_kmajor, bool b_kmajor, GemmParams p, bool allo
   hipStream_t st = kh::pick(s);
   const bool vec = kh::aligned16(p.A) && kh::aligned16(p.B) && (p.lda % 4 == 0) && (p.ldb % 4 == 0);
   Plan plan = make_plan(p.M, p.N, p.K, kh::ctx().num_cu > 0 ? kh::ctx().num_cu : 256, allow_split || softmax,
-                        softmax, EPI != EPI_UPDATE && EPI != EPI_RBM);
+                        softmax, EPI != EPI_UPDATE && EPI != EPI_RBM,
+                        a_kmajor && b_kmajor && EPI != EPI_UPDATE && EPI != EPI_RBM && KH_SCHED >= 2 && !old_staging_term);
   apply_plan(p, plan, a_kmajor, b_kmajor);
   const double flops = 2.0 * p.M * p.N * p.K;
   if (p.splitk == 1 && !softmax) {
