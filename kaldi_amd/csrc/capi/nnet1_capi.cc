@@ -27,7 +27,6 @@ struct RbmTrainer {
   CuRand<BaseFloat> cu_rand;
   MseProgress mse;
   CuMatrix<BaseFloat> pos_vis, pos_hid, neg_vis, neg_hid, dummy;
-  khEvent_t mse_start = NULL, mse_done = NULL;
 };
 
 // device rows (ld) -> CuMatrix, the copy Cache::GetBunch makes
@@ -221,16 +220,9 @@ int rbm1_cd1_bunch(void *h, const float *feats_dev, int ld, int rows, int cols) 
     t->cu_rand.AddGaussNoise(&t->neg_hid);
   }
   rbm.Reconstruct(t->neg_hid, &t->neg_vis);
-  CuDevice &dev = CuDevice::Instantiate();
-  {
-    // reconstruction error on the third stream beside the rest of the step (as in the tool)
-    dev.Order(dev.MainStream(), dev.AuxStream(), &t->mse_start);
-    CuStreamScope scope(dev.AuxStream());
-    t->mse.Eval(t->neg_vis, t->pos_vis, &t->dummy);
-  }
+  t->mse.Eval(t->neg_vis, t->pos_vis, &t->dummy);
   rbm.Propagate(t->neg_vis, &t->neg_hid);
   rbm.RbmUpdate(t->pos_vis, t->pos_hid, t->neg_vis, t->neg_hid);
-  dev.Order(dev.AuxStream(), dev.MainStream(), &t->mse_done);
   return 0;
   CAPI_CATCH(-1)
 }

@@ -36,6 +36,13 @@ struct GemmParams {
   int a_bytes, b_bytes;  // operand footprints when both are below 2 GiB (buffer addressing), else 0
   int tiles_m, tiles_n;
   int n_fastest;  // tile order inside an XCD's run of tiles: 0 = down the rows first, 1 = along the columns first
+  // EPI_RBM only, nk1 > 0: TWO products in one pass over the output.  K-tiles [0, nk1) multiply A, B into a first
+  // set of accumulators, K-tiles [nk1, 2 nk1) multiply A2, B2 (same shapes, leading dimensions and footprints)
+  // into a second one; K counts both ranges.  The epilogue then applies both statistics of the CD-1 step:
+  //   d = alpha * acc1 + beta * dW ; d = alpha2 * acc2 + d ; d = -l2 * W + d ; dW = d ; W += d
+  const float *A2, *B2;
+  float alpha2;
+  int nk1;
   float alpha, beta;
   float *C;
   int ldc;
@@ -162,6 +169,18 @@ __device__ __forceinline__ void epi_store(const GemmParams &p, int row, int col,
   }
 }
 
+// Both statistics of the RBM step on one element (GemmParams::nk1): the arithmetic of an EPI_AXPBY launch with the
+// negative statistics followed by an EPI_RBM launch with the positive ones, element for element.
+__device__ __forceinline__ void rbm_dual_store(const GemmParams &p, int row, int col, float v1, float v2) {
+  float *dw = p.C + (size_t)row * p.ldc + col;
+  const float wv = p.W[(size_t)row * p.ldw + col];
+  float d = (p.beta == 0.f) ? p.alpha * v1 : p.alpha * v1 + p.beta * *dw;
+  d = p.alpha2 * v2 + d;
+  d = -p.l2 * wv + d;
+  *dw = d;
+  p.Wout[(size_t)row * p.ldwout + col] = d + wv;
+}
+
 // BM x BN output tile, 4 waves arranged WAVES_M x WAVES_N x WK.  A K-tile is BKT = BK*WK deep and
 // wave-slice wk of it (BK = 32 k) goes to the waves with that wk: with WK > 1 the waves of a
 // workgroup split K among themselves and add their accumulators through LDS before the epilogue.
@@ -283,7 +302,19 @@ __device__ __forceinline__ void gemm_tile(const GemmParams &p, float *lds, const
     const v4i r = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0);
     return make_float4(__int_as_float(r.x), __int_as_float(r.y), __int_as_float(r.z), __int_as_float(r.w));
   };
+  // two products in one pass (EPI_RBM, p.nk1 > 0): K-tile kt >= nk1 is tile kt - nk1 of the second pair of operands
+  constexpr bool DUAL_EPI = (EPI == EPI_RBM);
+  const int nk1 = DUAL_EPI ? p.nk1 : 0;
+  const __amdgpu_buffer_rsrc_t rsrc_a2 = __builtin_amdgcn_make_buffer_rsrc((void *)(DUAL_EPI ? p.A2 : p.A), 0, p.a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_b2 = __builtin_amdgcn_make_buffer_rsrc((void *)(DUAL_EPI ? p.B2 : p.B), 0, p.b_bytes, 0x00020000);
   auto load_fast = [&](int kt) {
+    if (DUAL_EPI && nk1 > 0 && kt >= nk1) {
+#pragma unroll
+      for (int u = 0; u < A_UNITS; ++u) ra[u] = buf_load(rsrc_a2, oa[u], (kt - nk1) * a_step);
+#pragma unroll
+      for (int u = 0; u < B_UNITS; ++u) rb[u] = buf_load(rsrc_b2, ob[u], (kt - nk1) * b_step);
+      return;
+    }
 #pragma unroll
     for (int u = 0; u < A_UNITS; ++u) ra[u] = buf_load(rsrc_a, oa[u], kt * a_step);
 #pragma unroll
@@ -377,6 +408,21 @@ __device__ __forceinline__ void gemm_tile(const GemmParams &p, float *lds, const
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+  // first product's sums once the K loop has moved on to the second pair of operands (two products in one pass)
+  f32x16 acc1[DUAL_EPI ? TM : 1][DUAL_EPI ? TN : 1];
+  auto next_product = [&](int kt_now) {
+    if (DUAL_EPI && nk1 > 0 && kt_now == nk1) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          acc1[DUAL_EPI ? i : 0][DUAL_EPI ? j : 0] = acc[i][j];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        }
+    }
+  };
+
   // ---- operand fragments ------------------------------------------------------------------------
   // One group = 8 k = 4 MFMA steps per accumulator.  A fragment is fetched by RN single LDS read
   // instructions (one 16-byte read per 32-row block of a K-contiguous operand, four 4-byte reads
@@ -421,8 +467,13 @@ __device__ __forceinline__ void gemm_tile(const GemmParams &p, float *lds, const
     }
   };
   auto load_op = [&](int c, int kt) {
-    const float4 v = (c < A_UNITS) ? buf_load(rsrc_a, oa[c < A_UNITS ? c : 0], kt * a_step)
-                                   : buf_load(rsrc_b, ob[c < A_UNITS ? 0 : c - A_UNITS], kt * b_step);
+    float4 v;
+    if (DUAL_EPI && nk1 > 0 && kt >= nk1)
+      v = (c < A_UNITS) ? buf_load(rsrc_a2, oa[c < A_UNITS ? c : 0], (kt - nk1) * a_step)
+                        : buf_load(rsrc_b2, ob[c < A_UNITS ? 0 : c - A_UNITS], (kt - nk1) * b_step);
+    else
+      v = (c < A_UNITS) ? buf_load(rsrc_a, oa[c < A_UNITS ? c : 0], kt * a_step)
+                        : buf_load(rsrc_b, ob[c < A_UNITS ? 0 : c - A_UNITS], kt * b_step);
     if (c < A_UNITS) ra[c] = v; else rb[c - A_UNITS] = v;
   };
   // MFMAs of one K-tile out of LDS buffer `buf`, unpipelined (K tail, unaligned operands)
@@ -449,7 +500,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams &p, float *lds, const
   // Epilogue operand fetched under the main loop (the weight tile of the update GEMM): one
   // accumulator's worth per K-tile, so that the read-modify-write at the end starts with the old
   // weights already in registers instead of every workgroup hitting HBM at the same moment.
-  constexpr bool PREFETCH = (EPI == EPI_UPDATE);
+  constexpr bool PREFETCH = (EPI == EPI_UPDATE || EPI == EPI_RBM);  // (EPI_RBM: only in its 16-byte form, two products in one pass)
   static_assert(!(PREFETCH && WK > 1), "the update epilogue is not built for K split over waves");
   constexpr int NPRE = PREFETCH ? TM * TN : 1;
   float pre[NPRE][16];
@@ -573,7 +624,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams &p, float *lds, const
       }
     };
     auto steady = [&](auto par_tag) {
-      if (PREFETCH && (full_tile || epi_vec)) {
+      if (PREFETCH && (EPI == EPI_UPDATE ? (full_tile || epi_vec) : epi_vec)) {
 #pragma unroll
         for (int a = 0; a < NPRE; ++a)
           if (kt == a) {
@@ -664,7 +715,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams &p, float *lds, const
       }
     };
     auto steady = [&]() {
-      if (PREFETCH && (full_tile || epi_vec)) {
+      if (PREFETCH && (EPI == EPI_UPDATE ? (full_tile || epi_vec) : epi_vec)) {
 #pragma unroll
         for (int a = 0; a < NPRE; ++a)
           if (kt == a) {
@@ -672,12 +723,14 @@ __device__ __forceinline__ void gemm_tile(const GemmParams &p, float *lds, const
             npre = a + 1;
           }
       }
+      next_product(kt);
       tile_body(std::false_type());
     };
     for (; kt + 1 < nfull; ++kt) steady();
     KH_STAMP(4);
     const bool tail = nkt > nfull;  // the K tail, at most one partial tile
     if (tail) load_slow(nfull);
+    next_product(kt);
     tile_body(std::true_type());
     if (tail) {
       store_tiles(nfull & 1);
@@ -690,7 +743,54 @@ __device__ __forceinline__ void gemm_tile(const GemmParams &p, float *lds, const
   KH_STAMP(5);
   // ---- epilogue: accumulator register r of lane (li, lh) is C[(r&3) + 8*(r>>2) + 4*lh][li] ------
   if constexpr (WK == 1) {
-    if (PREFETCH && epi_vec) {
+    if (EPI == EPI_RBM && epi_vec) {
+      // Vector form of the RBM epilogue, two products in one pass (the host sets the footprints only then): as the
+      // update epilogue below -- accumulators turned through the wave's own region of LDS, 16-byte accesses -- with
+      // both sets of sums and the arithmetic of rbm_dual_store.  The first set is turned and kept in registers, then
+      // the second goes through the same region (LDS traffic of one wave is in order).
+      typedef int v4i_t __attribute__((ext_vector_type(4)));
+      const __amdgpu_buffer_rsrc_t rsrc_wout = __builtin_amdgcn_make_buffer_rsrc((void *)p.Wout, 0, p.wout_bytes, 0x00020000);
+      const __amdgpu_buffer_rsrc_t rsrc_c = __builtin_amdgcn_make_buffer_rsrc((void *)p.C, 0, p.c_bytes, 0x00020000);
+      float *xp = lds + wid * (32 * 36);
+      lds_barrier();  // every wave has read its last operand fragments
+#pragma unroll
+      for (int a = 0; a < TM * TN; ++a) {
+        if (a >= npre) prefetch_acc(a);
+        float4 old[4];
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) old[pass] = buf_load(rsrc_c, vec_off(a, pass, p.ldc), 0);
+        float4 v1[4];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) xp[((r & 3) + 8 * (r >> 2) + 4 * lh) * 36 + li] = acc1[DUAL_EPI ? a / TN : 0][DUAL_EPI ? a % TN : 0][r];
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) v1[pass] = *reinterpret_cast<const float4 *>(xp + ((lane >> 3) + 8 * pass) * 36 + (lane & 7) * 4);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) xp[((r & 3) + 8 * (r >> 2) + 4 * lh) * 36 + li] = acc[a / TN][a % TN][r];
+        const int col = n0 + wn0 + (a % TN) * 32 + (lane & 7) * 4;
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+          const float4 v2 = *reinterpret_cast<const float4 *>(xp + ((lane >> 3) + 8 * pass) * 36 + (lane & 7) * 4);
+          const float a1[4] = {v1[pass].x, v1[pass].y, v1[pass].z, v1[pass].w}, a2[4] = {v2.x, v2.y, v2.z, v2.w};
+          const float o[4] = {old[pass].x, old[pass].y, old[pass].z, old[pass].w};
+          float d[4], w[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float wv = pre[PREFETCH ? a : 0][4 * pass + e];
+            float t = (p.beta == 0.f) ? p.alpha * a1[e] : p.alpha * a1[e] + p.beta * o[e];
+            t = p.alpha2 * a2[e] + t;
+            t = -p.l2 * wv + t;
+            d[e] = t;
+            w[e] = t + wv;
+          }
+          if (col < p.N) {  // (rows past the matrix are dropped by the buffer bounds)
+            const v4i_t dv = {__float_as_int(d[0]), __float_as_int(d[1]), __float_as_int(d[2]), __float_as_int(d[3])};
+            __builtin_amdgcn_raw_buffer_store_b128(dv, rsrc_c, vec_off(a, pass, p.ldc), 0, 0);
+            const v4i_t wv4 = {__float_as_int(w[0]), __float_as_int(w[1]), __float_as_int(w[2]), __float_as_int(w[3])};
+            __builtin_amdgcn_raw_buffer_store_b128(wv4, rsrc_wout, vec_off(a, pass, p.ldwout), 0, KH_UPDATE_STORE_AUX);
+          }
+        }
+      }
+    } else if (EPI == EPI_UPDATE && epi_vec) {
       // Vector form of the update epilogue.  Each wave turns its accumulators, one 32 x 32 block at a time, through
       // a region of LDS of its own (the operand tiles are done with) so that a lane holds four consecutive columns
       // of a row: the old weights came in, and the new ones (and the momentum buffer) go out, 16 bytes per lane,
@@ -749,7 +849,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams &p, float *lds, const
         for (int r = 0; r < 16; ++r) {
           const int row = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
           const int col = n0 + wn0 + q * 32 + li;
-          if (PREFETCH && i * TN + q < npre) {
+          if (EPI == EPI_UPDATE && i * TN + q < npre) {
             // full tile, old weight already here (same arithmetic as epi_store<EPI_UPDATE>)
             float c = p.alpha * acc[i][q][r];
             if (p.mom != 0.f) c += p.mom * p.C[(size_t)row * p.ldc + col];
@@ -758,7 +858,8 @@ __device__ __forceinline__ void gemm_tile(const GemmParams &p, float *lds, const
             if (p.l2 != 0.f) wv = -p.l2 * wv + wv;
             p.Wout[(size_t)row * p.ldwout + col] = -p.lr * c + wv;
           } else if (row < p.M && col < p.N) {
-            epi_store<EPI>(p, row, col, epi_value<EPI>(p, acc[i][q][r], epi_aux<EPI>(p, row, col)), ks);
+            if (DUAL_EPI && nk1 > 0) rbm_dual_store(p, row, col, acc1[DUAL_EPI ? i : 0][DUAL_EPI ? q : 0][r], acc[i][q][r]);
+            else epi_store<EPI>(p, row, col, epi_value<EPI>(p, acc[i][q][r], epi_aux<EPI>(p, row, col)), ks);
           }
         }
   } else {

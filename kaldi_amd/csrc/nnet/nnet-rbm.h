@@ -26,10 +26,7 @@ class Rbm : public RbmBase {
  public:
   Rbm(MatrixIndexT dim_in, MatrixIndexT dim_out, Nnet *nnet)
       : RbmBase(dim_in, dim_out, nnet), vis_type_(BERNOULLI), hid_type_(BERNOULLI) {}
-  ~Rbm() {
-    if (inputs_ready_) hipK_event_destroy(inputs_ready_);
-    if (bias_done_) hipK_event_destroy(bias_done_);
-  }
+  ~Rbm() {}
 
   ComponentType GetType() const { return kRbm; }
 
@@ -95,27 +92,15 @@ class Rbm : public RbmBase {
     vis_hid_corr_.Resize(vis_hid_.NumRows(), vis_hid_.NumCols());  // no-op after the first call
     vis_bias_corr_.Resize(vis_bias_.Dim());
     hid_bias_corr_.Resize(hid_bias_.Dim());
-    CuDevice &dev = CuDevice::Instantiate();
-    if (dev.Profiling()) {
-      CU_SAFE_CALL(hipF_rbm_update(S(), pos_vis.NumRows(), output_dim_, input_dim_, pos_vis.Data(), pos_vis.Stride(),
-                                   pos_hid.Data(), pos_hid.Stride(), neg_vis.Data(), neg_vis.Stride(), neg_hid.Data(),
-                                   neg_hid.Stride(), learn_rate_, momentum_, l2_penalty_, vis_hid_.Data(),
-                                   vis_hid_.Stride(), vis_hid_corr_.Data(), vis_hid_corr_.Stride(), vis_bias_.Data(),
-                                   vis_bias_corr_.Data(), hid_bias_.Data(), hid_bias_corr_.Data()));
-      return;
-    }
-    // The bias half (two column-sum kernels that only read the activations) on the third stream,
-    // beside the two statistic GEMMs; joined before returning, so callers see one in-order stream.
-    dev.Order(dev.Stream(), dev.AuxStream(), &inputs_ready_);
-    CU_SAFE_CALL(hipF_rbm_update_bias(dev.AuxStream(), pos_vis.NumRows(), output_dim_, input_dim_, pos_vis.Data(),
-                                      pos_vis.Stride(), pos_hid.Data(), pos_hid.Stride(), neg_vis.Data(), neg_vis.Stride(),
-                                      neg_hid.Data(), neg_hid.Stride(), learn_rate_, momentum_, vis_bias_.Data(),
-                                      vis_bias_corr_.Data(), hid_bias_.Data(), hid_bias_corr_.Data()));
-    CU_SAFE_CALL(hipF_rbm_update_weights(S(), pos_vis.NumRows(), output_dim_, input_dim_, pos_vis.Data(), pos_vis.Stride(),
-                                         pos_hid.Data(), pos_hid.Stride(), neg_vis.Data(), neg_vis.Stride(), neg_hid.Data(),
-                                         neg_hid.Stride(), learn_rate_, momentum_, l2_penalty_, vis_hid_.Data(),
-                                         vis_hid_.Stride(), vis_hid_corr_.Data(), vis_hid_corr_.Stride()));
-    dev.Order(dev.AuxStream(), dev.Stream(), &bias_done_);
+    // One stream: both weight statistics in one launch where the operands allow it, then both bias statistics in
+    // one small launch.  (The bias half and the reconstruction error used to run on a second stream beside the
+    // GEMMs: the event packets that fork and join the streams left ~6 us gaps in the main stream's queue, three
+    // per step, more than the small kernels take on their own.)
+    CU_SAFE_CALL(hipF_rbm_update(S(), pos_vis.NumRows(), output_dim_, input_dim_, pos_vis.Data(), pos_vis.Stride(),
+                                 pos_hid.Data(), pos_hid.Stride(), neg_vis.Data(), neg_vis.Stride(), neg_hid.Data(),
+                                 neg_hid.Stride(), learn_rate_, momentum_, l2_penalty_, vis_hid_.Data(),
+                                 vis_hid_.Stride(), vis_hid_corr_.Data(), vis_hid_corr_.Stride(), vis_bias_.Data(),
+                                 vis_bias_corr_.Data(), hid_bias_.Data(), hid_bias_corr_.Data()));
   }
 
   RbmNodeType VisType() const { return vis_type_; }
@@ -170,7 +155,6 @@ class Rbm : public RbmBase {
     if (!binary) os << "\n";
   }
 
-  khEvent_t inputs_ready_ = NULL, bias_done_ = NULL;
   CuMatrix<BaseFloat> vis_hid_;
   CuVector<BaseFloat> vis_bias_;
   CuVector<BaseFloat> hid_bias_;

@@ -71,7 +71,6 @@ int main(int argc, char *argv[]) {
     MseProgress mse;
 
     FeatureUploader uploader(cachesize);
-    khEvent_t mse_start = NULL, mse_done = NULL;
     CuMatrix<BaseFloat> feats_transf, pos_vis, pos_hid, neg_vis, neg_hid, dummy_mse_mat;
     std::vector<int32> dummy_cache_vec;
     CuStlVector<int32> dummy_targets;
@@ -109,17 +108,9 @@ int main(int argc, char *argv[]) {
         }
         // negative phase
         rbm.Reconstruct(neg_hid, &neg_vis);
-        {
-          // the reconstruction error only reads neg_vis and pos_vis: on the third stream, beside the rest
-          // of the step (RbmUpdate queues its bias kernels behind it there); joined below
-          CuDevice &dev = CuDevice::Instantiate();
-          dev.Order(dev.MainStream(), dev.AuxStream(), &mse_start);
-          CuStreamScope scope(dev.AuxStream());
-          mse.Eval(neg_vis, pos_vis, &dummy_mse_mat);
-        }
+        mse.Eval(neg_vis, pos_vis, &dummy_mse_mat);
         rbm.Propagate(neg_vis, &neg_hid);
         rbm.RbmUpdate(pos_vis, pos_hid, neg_vis, neg_hid);
-        CuDevice::Instantiate().Order(CuDevice::Instantiate().AuxStream(), CuDevice::Instantiate().MainStream(), &mse_done);
         tot_t += pos_vis.NumRows();
       }
       if (feature_reader.Done()) break;
