@@ -83,6 +83,8 @@ int hipK_device_props(int *num_cu, int *wave_size, char *arch_name, size_t arch_
  * cu-matrix-inl.h:349-357; events do not stall the stream). */
 typedef void *khEvent_t; /* hipEvent_t */
 int hipK_event_create(khEvent_t *ev);
+/* an event that only orders streams (hipK_stream_wait_event): no time stamps are taken when it is recorded */
+int hipK_event_create_ordering(khEvent_t *ev);
 int hipK_event_destroy(khEvent_t ev);
 int hipK_event_record(khEvent_t ev, khStream_t s);
 int hipK_event_synchronize(khEvent_t ev); /* blocking */

@@ -438,6 +438,14 @@ KH_EXPORT int hipK_event_create(khEvent_t *ev) {
   *ev = (khEvent_t)e;
   return KH_OK;
 }
+KH_EXPORT int hipK_event_create_ordering(khEvent_t *ev) {
+  KH_CHECK_INIT();
+  KH_REQUIRE(ev != nullptr);
+  hipEvent_t e;
+  KH_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  *ev = (khEvent_t)e;
+  return KH_OK;
+}
 KH_EXPORT int hipK_event_destroy(khEvent_t ev) {
   if (!ev) return KH_OK;
   KH_HIP(hipEventDestroy((hipEvent_t)ev));

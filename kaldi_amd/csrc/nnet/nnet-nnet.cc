@@ -187,7 +187,19 @@ void Nnet::Backpropagate(const CuMatrix<BaseFloat> &in_err, CuMatrix<BaseFloat> 
     if (nnet_[i]->GetType() != Component::kBiasedLinearity) return;
     BiasedLinearity *bl = static_cast<BiasedLinearity *>(nnet_[i]);
     bl->SetDoubleBuffer(dp_ranks_ == 1 || dp_gather_);
-    if (bl->UpdateKeepsOldWeights() || dp_ranks_ > 1) dev.Order(dev.MainStream(), dev.SideStream(), &layer_events_[i]);
+    if (dp_ranks_ > 1) {
+      // data-parallel: only the mark in the main stream; whoever needs it waits for it when its work is queued
+      if (layer_events_[i] == NULL) CU_SAFE_CALL(hipK_event_create_ordering(&layer_events_[i]));
+      CU_SAFE_CALL(hipK_event_record(layer_events_[i], dev.MainStream()));
+    } else if (bl->UpdateKeepsOldWeights()) {
+      dev.Order(dev.MainStream(), dev.SideStream(), &layer_events_[i]);
+    }
+  };
+  // to be called after the back-propagation of layer i has been queued (data-parallel): "layer i's weights read"
+  auto weights_read = [&](int32 i) {
+    if (static_cast<int32>(read_events_.size()) < L) read_events_.resize(L, NULL);
+    if (read_events_[i] == NULL) CU_SAFE_CALL(hipK_event_create_ordering(&read_events_[i]));
+    CU_SAFE_CALL(hipK_event_record(read_events_[i], dev.MainStream()));
   };
   // Single GPU: the updates of the <biasedlinearity> layers are written down here and launched together behind
   // the back-propagation pass (hipF_affine_update_group).  Same result as the reference's order: a layer's
@@ -222,7 +234,6 @@ void Nnet::Backpropagate(const CuMatrix<BaseFloat> &in_err, CuMatrix<BaseFloat> 
         dp_err_all_.resize(L);
       }
       if (static_cast<int32>(grad_events_.size()) < L) grad_events_.resize(L, NULL);
-      if (static_cast<int32>(read_events_.size()) < L) read_events_.resize(L, NULL);
       const int32 rows = input.NumRows();
       {
         CuStreamScope scope(dev.AuxStream());  // (a first-time Resize zero-fills on this stream)
@@ -244,7 +255,7 @@ void Nnet::Backpropagate(const CuMatrix<BaseFloat> &in_err, CuMatrix<BaseFloat> 
                                   static_cast<size_t>(rows) * err.Stride()));
       dev.Order(dev.AuxStream(), dev.SideStream(), &grad_events_[i]);
       // without a second weight buffer (L1 penalty) the step must also wait for this layer's back-propagation
-      if (!bl->UpdateKeepsOldWeights()) dev.Order(dev.MainStream(), dev.SideStream(), &read_events_[i]);
+      if (!bl->UpdateKeepsOldWeights()) CU_SAFE_CALL(hipK_stream_wait_event(dev.SideStream(), read_events_[i]));
       CuStreamScope scope(dev.SideStream());
       bl->UpdateWeights(dp_in_all_[i], dp_err_all_[i]);
       bl->UpdateBias(dp_err_all_[i]);
@@ -261,7 +272,6 @@ void Nnet::Backpropagate(const CuMatrix<BaseFloat> &in_err, CuMatrix<BaseFloat> 
         dp_layer_grad_.resize(L, NULL);
         dp_layer_grad_size_.resize(L, 0);
         grad_events_.resize(L, NULL);
-        read_events_.resize(L, NULL);
       }
       const bool shard = dp_shard_ && bl->CanShard(dp_ranks_);
       const size_t need = shard ? bl->ShardedGradientSize() : bl->GradientSize();
@@ -277,13 +287,14 @@ void Nnet::Backpropagate(const CuMatrix<BaseFloat> &in_err, CuMatrix<BaseFloat> 
         // (the sharded form relies on zeros in the padding of the gradient's rows)
         CU_SAFE_CALL(hipK_memset_async(dev.SideStream(), p, 0, need * sizeof(BaseFloat)));
       }
+      CU_SAFE_CALL(hipK_stream_wait_event(dev.SideStream(), layer_events_[i]));  // this layer's error exists
       {
         CuStreamScope scope(dev.SideStream());
         if (shard) bl->ComputeGradientPitched(input, err, dp_layer_grad_[i]);
         else bl->ComputeGradient(input, err, dp_layer_grad_[i]);
       }
       dev.Order(dev.SideStream(), dev.AuxStream(), &grad_events_[i]);
-      dev.Order(dev.MainStream(), dev.AuxStream(), &read_events_[i]);
+      CU_SAFE_CALL(hipK_stream_wait_event(dev.AuxStream(), read_events_[i]));  // its back-propagation has read the weights
       {
         CuStreamScope scope(dev.AuxStream());
         if (shard) {
@@ -326,6 +337,26 @@ void Nnet::Backpropagate(const CuMatrix<BaseFloat> &in_err, CuMatrix<BaseFloat> 
     uc->Update(input, err);
   };
 
+  // Data-parallel: the whole back-propagation chain is queued first -- with one mark in front of and one behind
+  // every layer's step -- and only then each layer's gradient, exchange and step on the other two streams,
+  // which wait for those marks.  Queuing a layer's exchange takes the host 100 us and more (a dozen calls into
+  // HIP and RCCL); done between the back-propagation launches it starved the main stream of work (timeline of
+  // the one-GPU rehearsal: 90-150 us gaps between back-propagation kernels).
+  struct PendingUpdate {
+    int32 i;
+    const CuMatrix<BaseFloat> *input, *err;
+  };
+  std::vector<PendingUpdate> pending;
+  auto update_or_defer = [&](int32 i, const CuMatrix<BaseFloat> &input, const CuMatrix<BaseFloat> &err) {
+    if (overlap && dp_ranks_ > 1 && nnet_[i]->IsUpdatable() && nnet_[i]->GetType() == Component::kBiasedLinearity) {
+      weights_read(i);
+      const PendingUpdate pu = {i, &input, &err};
+      pending.push_back(pu);
+      return;
+    }
+    update(i, input, err);
+  };
+
   const CuMatrix<BaseFloat> *err = &in_err;  // error w.r.t. the output of layer i
   int32 i = L - 1;
   while (i >= 0) {
@@ -344,17 +375,18 @@ void Nnet::Backpropagate(const CuMatrix<BaseFloat> &in_err, CuMatrix<BaseFloat> 
       CuMatrix<BaseFloat> *below2 = (i - 1 > 0) ? &backpropagate_buf_[i - 2] : out_err;
       err_ready(i);
       if (below2 != NULL) bl->BackpropagateFused(*err, propagate_buf_[i], below2);
-      update(i, propagate_buf_[i], *err);
+      update_or_defer(i, propagate_buf_[i], *err);
       err = below2;
       i -= 2;
       continue;
     }
     err_ready(i);
     if (below != NULL) comp->Backpropagate(*err, below);
-    update(i, propagate_buf_[i], *err);
+    update_or_defer(i, propagate_buf_[i], *err);
     err = below;
     --i;
   }
+  for (size_t k = 0; k < pending.size(); ++k) update(pending[k].i, *pending[k].input, *pending[k].err);
   if (!deferred_updates_.empty()) {
     CuProfileScope p("BiasedLinearity::Update");
     CU_SAFE_CALL(hipF_affine_update_group(dev.Stream(), static_cast<int32>(deferred_updates_.size()), &deferred_updates_[0]));
