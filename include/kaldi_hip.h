@@ -305,7 +305,8 @@ int hipF_affine_update_fused(khStream_t s, int32_t N, int32_t O, int32_t I, cons
  * 256-frame update is short, so launched one by one every layer pays a kernel boundary and all its
  * workgroups load, multiply and store in step; in one long grid the workgroups of a compute unit drift out
  * of phase and one's loads and stores run under another's MFMAs.  Items that do not qualify for the
- * grouped kernel (operands not 16-byte aligned, more than 2 GiB) are launched on their own. */
+ * grouped kernel (operands not 16-byte aligned, more than 2 GiB) are launched on their own.  Every item is
+ * checked before anything is launched: a call that returns an argument error has changed nothing. */
 typedef struct {
   int32_t N, O, I;
   const float *e; int32_t lde;

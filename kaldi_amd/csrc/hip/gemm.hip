@@ -703,12 +703,16 @@ KH_EXPORT int hipF_affine_update_group(khStream_t s, int32_t count, const khAffi
     flops = 0.0;
     return kh::launch_status();
   };
+  // every item is checked before anything is launched: a refused call has changed nothing
   for (int i = 0; i < count; ++i) {
     const khAffineUpdate &u = items[i];
     KH_REQUIRE(u.N > 0 && u.O > 0 && u.I > 0);
     KH_REQUIRE(u.e && u.in && u.W_in && u.W_out && u.bias && u.lde >= u.O && u.ldin >= u.I && u.ldw_in >= u.I && u.ldw_out >= u.I);
     KH_REQUIRE(u.momentum == 0.f || (u.corr != nullptr && u.bcorr != nullptr));
     KH_REQUIRE(u.corr == nullptr || u.ldcorr >= u.I);
+  }
+  for (int i = 0; i < count; ++i) {
+    const khAffineUpdate &u = items[i];
     GemmParams p = base_params(u.O, u.I, u.N, u.e, u.lde, u.in, u.ldin, u.corr, u.ldcorr);
     p.alpha = u.gscale;
     p.mom = u.momentum;

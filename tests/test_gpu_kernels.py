@@ -552,10 +552,13 @@ def test_affine_update_group_equals_single_launches(hip, mom):
             assert np.array_equal(s["ba"].numpy(), s["bb"].numpy()), (rnd_no, shapes[k])
             if mom:
                 assert np.array_equal(s["ca"].numpy(), s["cb"].numpy()) and np.array_equal(s["bca"].numpy(), s["bcb"].numpy())
-    # an item with a bad argument is refused
-    items[0].lde = 1
+    # a bad argument in the LAST item: the call is refused and no item before it has run
+    before = [s["Wb"].numpy() for s in sets]
+    items[len(sets) - 1].lde = 1
     with pytest.raises(h.HipError):
-        h.call("hipF_affine_update_group", None, 1, ctypes.cast(items, ctypes.c_void_p))
+        h.call("hipF_affine_update_group", None, len(sets), ctypes.cast(items, ctypes.c_void_p))
+    for s, w in zip(sets, before):
+        assert np.array_equal(s["Wb"].numpy(), w)
 
 
 @pytest.mark.parametrize("N,O_,I", [(256, 1483, 1024), (256, 9000, 2048), (37, 50, 24), (64, 5000, 64), (64, 12000, 128)])
