@@ -35,7 +35,7 @@ void Cache::AddData(const CuMatrix<BaseFloat> &features, const std::vector<int32
     filling_pos_ = 0;
     targets_on_device_ = false;
     // rows that did not fit last time come first
-    int32 leftover = features_leftover_.NumRows();
+    int32 leftover = leftover_rows_;
     if (leftover > static_cast<int32>(cachesize_)) {
       KALDI_WARN << "Too small feature cache: " << cachesize_ << ", truncating: " << leftover - cachesize_
                  << " frames from previous segment leftover";
@@ -44,7 +44,10 @@ void Cache::AddData(const CuMatrix<BaseFloat> &features, const std::vector<int32
     if (leftover > 0) {
       features_.CopyRowsFromMat(leftover, features_leftover_, 0, 0);
       std::copy(targets_leftover_.begin(), targets_leftover_.begin() + leftover, targets_.begin());
-      features_leftover_.Destroy();
+      // The buffer keeps its memory (the next overflow is written behind this copy, on the same stream): freeing
+      // it would wait for the whole device, i.e. for every training step still queued from the previous cache,
+      // and the fill of this cache would no longer run beside them.
+      leftover_rows_ = 0;
       targets_leftover_.clear();
       filling_pos_ += leftover;
     }
@@ -62,6 +65,7 @@ void Cache::AddData(const CuMatrix<BaseFloat> &features, const std::vector<int32
   if (rest > 0) {
     features_leftover_.Resize(rest, features_.NumCols());
     features_leftover_.CopyRowsFromMat(rest, features, fill, 0);
+    leftover_rows_ = rest;
     targets_leftover_.assign(targets.begin() + fill, targets.end());
   }
   filling_pos_ += fill;
@@ -174,7 +178,7 @@ void CacheTgtMat::AddData(const CuMatrix<BaseFloat> &features, const CuMatrix<Ba
   if (state_ == EMPTY) {
     state_ = FILLING;
     filling_pos_ = 0;
-    int32 leftover = features_leftover_.NumRows();
+    int32 leftover = leftover_rows_;
     if (leftover > static_cast<int32>(cachesize_)) {
       KALDI_WARN << "Too small feature cache: " << cachesize_ << ", truncating: " << leftover - cachesize_
                  << " frames from previous segment leftover";
@@ -183,8 +187,7 @@ void CacheTgtMat::AddData(const CuMatrix<BaseFloat> &features, const CuMatrix<Ba
     if (leftover > 0) {
       features_.CopyRowsFromMat(leftover, features_leftover_, 0, 0);
       targets_.CopyRowsFromMat(leftover, targets_leftover_, 0, 0);
-      features_leftover_.Destroy();
-      targets_leftover_.Destroy();
+      leftover_rows_ = 0;  // (both buffers keep their memory: see Cache::AddData)
       filling_pos_ += leftover;
     }
   }
@@ -201,6 +204,7 @@ void CacheTgtMat::AddData(const CuMatrix<BaseFloat> &features, const CuMatrix<Ba
     features_leftover_.CopyRowsFromMat(rest, features, fill, 0);
     targets_leftover_.Resize(rest, targets_.NumCols());
     targets_leftover_.CopyRowsFromMat(rest, targets, fill, 0);
+    leftover_rows_ = rest;
   }
   filling_pos_ += fill;
   if (filling_pos_ == cachesize_) state_ = FULL;

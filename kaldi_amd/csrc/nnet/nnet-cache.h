@@ -54,6 +54,7 @@ class Cache {
 
   CuMatrix<BaseFloat> features_, features_random_, features_leftover_;
   std::vector<int32> targets_, targets_random_, targets_leftover_;
+  int32 leftover_rows_ = 0;  // rows of features_leftover_ waiting for the next cache (its allocation may be larger)
   CuStlVector<int32> targets_device_;
   std::vector<int32> randmask_;
   CuStlVector<int32> randmask_device_;
@@ -83,6 +84,7 @@ class CacheTgtMat {
   bool randomized_;
   CuMatrix<BaseFloat> features_, features_random_, features_leftover_;
   CuMatrix<BaseFloat> targets_, targets_random_, targets_leftover_;
+  int32 leftover_rows_ = 0;  // rows of the leftover buffers waiting for the next cache
   std::vector<int32> randmask_;
   CuStlVector<int32> randmask_device_;
 };

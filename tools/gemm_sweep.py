@@ -25,7 +25,7 @@ def bench(fn, iters=30):
 def main():
     which = sys.argv[1] if len(sys.argv) > 1 else "swbd"
     h.init(-1)
-    N = 256
+    N = int(sys.argv[2]) if len(sys.argv) > 2 else 256
     shapes = [(2048, 2048), (2048, 1320), (9000, 2048)] if which == "swbd" else [(1024, 1024), (1024, 440), (1483, 1024)]
     rs = np.random.RandomState(0)
     for (O_, I) in shapes:
