@@ -133,6 +133,12 @@ __device__ __forceinline__ float block_max(float v, float *red) {
   return t;
 }
 
+// a * b + c as ONE fused operation, written out.  Where the sum of two products is left to the compiler
+// (x * y + a * b) it may fuse either product into the add, and which one it picks can differ between two
+// instantiations of the same source: the momentum term of the update formulas is pinned with this so that every
+// kernel that applies them gives the same bits.
+__device__ __forceinline__ float mul_add(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+
 // 1/(1+exp(-x)) in fp32.  expf() here is the correctly scaled library call (not the fast
 // intrinsic) so results stay within a few ulp of the reference's double evaluation.
 __device__ __forceinline__ float sigmoidf(float x) { return 1.0f / (1.0f + expf(-x)); }

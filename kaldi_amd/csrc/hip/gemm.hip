@@ -286,7 +286,7 @@ __global__ __launch_bounds__(1024) void bias_update_kernel(const float *e, int l
 #pragma unroll
     for (int i = 0; i < 16; ++i) t += part[i][lane];
     float bc = g * t;
-    if (mom != 0.f) bc += mom * bcorr[c];
+    if (mom != 0.f) bc = kh::mul_add(mom, bcorr[c], bc);
     if (bcorr) bcorr[c] = bc;
     bias[c] = -lr * bc + bias[c];
   }
@@ -400,7 +400,7 @@ __global__ __launch_bounds__(256) void affine_apply_kernel(int O, int I, const f
 #pragma unroll
     for (int i = 0; i < VEC; ++i) {
       float cc = g * gv[i];
-      if (mom != 0.f) cc += mom * cv[i];
+      if (mom != 0.f) cc = kh::mul_add(mom, cv[i], cc);
       cv[i] = cc;
       float w = wv[i];
       if (l2 != 0.f) w = -l2 * w + w;
@@ -420,7 +420,7 @@ __global__ void bias_apply_kernel(int O, const float *bgrad, float g, float mom,
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= O) return;
   float bc = g * bgrad[c];
-  if (mom != 0.f) bc += mom * bcorr[c];
+  if (mom != 0.f) bc = kh::mul_add(mom, bcorr[c], bc);
   if (bcorr) bcorr[c] = bc;
   bias[c] = -lr * bc + bias[c];
 }

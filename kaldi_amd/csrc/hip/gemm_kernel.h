@@ -154,7 +154,7 @@ __device__ __forceinline__ void epi_store(const GemmParams &p, int row, int col,
     p.C[(size_t)row * p.ldc + col] = val;
   } else if (EPI == EPI_UPDATE) {
     float c = p.alpha * val;
-    if (p.mom != 0.f) c += p.mom * p.C[(size_t)row * p.ldc + col];
+    if (p.mom != 0.f) c = kh::mul_add(p.mom, p.C[(size_t)row * p.ldc + col], c);
     if (p.C) p.C[(size_t)row * p.ldc + col] = c;
     float wv = p.W[(size_t)row * p.ldw + col];
     if (p.l2 != 0.f) wv = -p.l2 * wv + wv;
@@ -759,6 +759,13 @@ __device__ __forceinline__ void gemm_tile(const GemmParams &p, float *lds, const
         float4 old[4];
 #pragma unroll
         for (int pass = 0; pass < 4; ++pass) old[pass] = buf_load(rsrc_c, vec_off(a, pass, p.ldc), 0);
+        // one wait for every load of this accumulator's epilogue, before its first store (see the update epilogue)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass)
+          asm volatile("" : "+v"(old[pass].x), "+v"(old[pass].y), "+v"(old[pass].z), "+v"(old[pass].w));
+#pragma unroll
+        for (int r = 0; r < 16; ++r) asm volatile("" : "+v"(pre[PREFETCH ? a : 0][r]));
         float4 v1[4];
 #pragma unroll
         for (int r = 0; r < 16; ++r) xp[((r & 3) + 8 * (r >> 2) + 4 * lh) * 36 + li] = acc1[DUAL_EPI ? a / TN : 0][DUAL_EPI ? a % TN : 0][r];
@@ -805,9 +812,22 @@ __device__ __forceinline__ void gemm_tile(const GemmParams &p, float *lds, const
       float *xp = lds + wid * (32 * 36);
       lds_barrier();  // every wave has read its last operand fragments
       KH_CYC(14);
+      // Every load of the epilogue is waited for HERE, before its first store.  The memory counter retires loads
+      // and stores in order, and the compiler, which cannot know that the old weights arrived during the K loop,
+      // otherwise places a counted wait in front of each pass's use of them -- a wait that, from the third pass
+      // on, also waits for the write-through stores of the passes before it (in-kernel stamps: ~1400 cycles per
+      // store instruction, 11 k cycles for the eight of a 64 x 32 wave tile).  After this wait the registers are
+      // "touched" by empty asm statements, so the compiler sees them as plain values.
+#pragma unroll
+      for (int a = 0; a < TM * TN; ++a)
+        if (a >= npre) prefetch_acc(a);  // (K shorter than the number of accumulators)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int a = 0; a < TM * TN; ++a)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) asm volatile("" : "+v"(pre[PREFETCH ? a : 0][r]));
 #pragma unroll
       for (int a = 0; a < TM * TN; ++a) {
-        if (a >= npre) prefetch_acc(a);  // (K shorter than the number of accumulators)
 #pragma unroll
         for (int r = 0; r < 16; ++r) xp[((r & 3) + 8 * (r >> 2) + 4 * lh) * 36 + li] = acc[a / TN][a % TN][r];
         if (a == 0) {
@@ -815,13 +835,25 @@ __device__ __forceinline__ void gemm_tile(const GemmParams &p, float *lds, const
           KH_CYC(15);
         }
         const int col = n0 + wn0 + (a % TN) * 32 + (lane & 7) * 4;
+        // momentum: the old corrections of all four passes in flight together, one wait (which also waits for
+        // the stores of the accumulator before this one: once per accumulator instead of once per pass)
+        float4 oldc[4];
+        if (p.mom != 0.f) {
+#pragma unroll
+          for (int pass = 0; pass < 4; ++pass) oldc[pass] = buf_load(rsrc_c, vec_off(a, pass, p.ldc), 0);
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+          for (int pass = 0; pass < 4; ++pass)
+            asm volatile("" : "+v"(oldc[pass].x), "+v"(oldc[pass].y), "+v"(oldc[pass].z), "+v"(oldc[pass].w));
+        }
 #pragma unroll
         for (int pass = 0; pass < 4; ++pass) {
           const float4 v = *reinterpret_cast<const float4 *>(xp + ((lane >> 3) + 8 * pass) * 36 + (lane & 7) * 4);
           float c[4] = {p.alpha * v.x, p.alpha * v.y, p.alpha * v.z, p.alpha * v.w};
           if (p.mom != 0.f) {
-            const float4 o = buf_load(rsrc_c, vec_off(a, pass, p.ldc), 0);
-            c[0] += p.mom * o.x; c[1] += p.mom * o.y; c[2] += p.mom * o.z; c[3] += p.mom * o.w;
+            const float4 o = oldc[pass];
+            c[0] = kh::mul_add(p.mom, o.x, c[0]); c[1] = kh::mul_add(p.mom, o.y, c[1]);
+            c[2] = kh::mul_add(p.mom, o.z, c[2]); c[3] = kh::mul_add(p.mom, o.w, c[3]);
           }
           float w[4];
 #pragma unroll
@@ -852,7 +884,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams &p, float *lds, const
           if (EPI == EPI_UPDATE && i * TN + q < npre) {
             // full tile, old weight already here (same arithmetic as epi_store<EPI_UPDATE>)
             float c = p.alpha * acc[i][q][r];
-            if (p.mom != 0.f) c += p.mom * p.C[(size_t)row * p.ldc + col];
+            if (p.mom != 0.f) c = kh::mul_add(p.mom, p.C[(size_t)row * p.ldc + col], c);
             if (p.C) p.C[(size_t)row * p.ldc + col] = c;
             float wv = pre[PREFETCH ? i * TN + q : 0][r];
             if (p.l2 != 0.f) wv = -p.l2 * wv + wv;
@@ -987,7 +1019,7 @@ __device__ __forceinline__ void bias_update_tile(const GemmParams &p, float *lds
 #pragma unroll
     for (int i = 0; i < 16; ++i) t += lds[i * 64 + tid];
     float bc = p.alpha * t;
-    if (p.mom != 0.f) bc += p.mom * p.bcorr[c];
+    if (p.mom != 0.f) bc = kh::mul_add(p.mom, p.bcorr[c], bc);
     if (p.bcorr) p.bcorr[c] = bc;
     p.bias_io[c] = -p.lr * bc + p.bias_io[c];
   }
