@@ -214,6 +214,8 @@ def main():
         # utterance-sharded inference: every rank works through its own utterances, no collective
         trainer = nn.Trainer(model_path)
         lens = np.random.RandomState(777 + rank).randint(300, 1201, 16)
+        if os.environ.get("KALDI_BENCH_UTT_ROWS"):   # (probe: every "utterance" this many rows, e.g. a batch of utterances)
+            lens[:] = int(os.environ["KALDI_BENCH_UTT_ROWS"])
         utts = [h.DevMatrix.from_numpy(rs.standard_normal((int(n), dims[0])).astype(np.float32)) for n in lens]
         post = h.DevMatrix(int(lens.max()), dims[-1])
         frames_of = lambda i: int(lens[i % len(utts)])

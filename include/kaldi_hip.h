@@ -253,6 +253,13 @@ int hipK_gemm_timing_spans(double *start_ms, double *dur_ms, double *gflop, int 
  * the environment variable KALDI_HIP_GEMM_FORCE="bm,bn,splitk". */
 int hipK_gemm_force_plan(int bm, int bn, int splitk);
 
+/* on != 0: every following GEMM sums each output element's K range in one piece, in K order (no split of K over
+ * workgroups or over the waves of a workgroup), whatever the number of rows: a row of the result then has the same
+ * bits whether it is computed alone or together with other rows.  For callers that batch independent rows
+ * (utterances) into one call and promise results that do not depend on the batching.  Off by default: the split
+ * plans are the faster ones for short products. */
+int hipK_gemm_row_invariant(int on);
+
 /* Pre-sizes the scratch workspace of the library's default stream (split-K slabs of hipF_gemm and of the
  * fused entry points).  The library grows the workspace on demand (blocking: device synchronise + free +
  * allocate), so callers only need this to keep that out of a timed or captured region. */

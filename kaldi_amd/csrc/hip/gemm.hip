@@ -70,6 +70,9 @@ struct Plan {
 // the kernel that sums the slabs.
 const bool old_staging_term = getenv("KALDI_HIP_PLAN_OLD_STAGING") != nullptr;  // for A/B measurements
 int force_bm = -1, force_bn = -1, force_s = -1;
+// hipK_gemm_row_invariant: only plans that sum a row's K range in one piece (no split over workgroups or waves), so
+// that a row's result does not depend on how many other rows share the call
+bool row_invariant = false;
 bool env_read = false;
 
 Plan make_plan(int M, int N, int K, int num_cu, bool allow_split, bool always_slabs, bool allow_wk, bool kmajor_whole_tile) {
@@ -87,13 +90,13 @@ Plan make_plan(int M, int N, int K, int num_cu, bool allow_split, bool always_sl
   const double cyc_per_us = 2400.0;  // shader clock under sustained fp32 MFMA load (2.38-2.40 GHz by s_memtime / s_memrealtime)
   for (int c = 0; c < ncfg; ++c) {
     const TileCfg &t = kCfgs[c];
-    if (t.wk > 1 && !allow_wk) continue;
+    if (t.wk > 1 && (!allow_wk || row_invariant)) continue;
     if (force_bm > 0 ? (t.bm != force_bm || t.bn != force_bn) : !(c == 0 || (t.wk > 1 && wk_on))) continue;
     const int bkt = kBK * t.wk;
     const int ktiles = (K + bkt - 1) / bkt;
     const int tm = (M + t.bm - 1) / t.bm, tn = (N + t.bn - 1) / t.bn;
     for (int s = 1; s <= 16; s *= 2) {
-      if (s > 1 && !allow_split) break;
+      if (s > 1 && (!allow_split || row_invariant)) break;
       if (force_s > 0 && s != force_s) continue;
       if (s > ktiles) break;
       const int kt_per = (ktiles + s - 1) / s;
@@ -488,6 +491,11 @@ KH_EXPORT int hipK_gemm_force_plan(int bm, int bn, int splitk) {
   force_bm = bm > 0 ? bm : -1;
   force_bn = bn > 0 ? bn : -1;
   force_s = splitk > 0 ? splitk : -1;
+  return KH_OK;
+}
+
+KH_EXPORT int hipK_gemm_row_invariant(int on) {
+  row_invariant = on != 0;
   return KH_OK;
 }
 

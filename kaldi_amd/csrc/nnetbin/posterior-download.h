@@ -9,6 +9,10 @@
 // writer thread waits for each copy in submission order, raises the reference's error if a count is not
 // zero, writes the matrix from the pinned buffer and frees the slot.  An error on that thread surfaces at
 // the next Begin / Close.
+//
+// A slot can carry several utterances computed as ONE matrix (their rows one after another): BeginBatch,
+// AddPiece per utterance, Finish once the row count is known, SubmitBatch.  Each utterance keeps its own
+// NaN / inf counts and its own table entry.
 #ifndef KALDI_AMD_NNETBIN_POSTERIOR_DOWNLOAD_H_
 #define KALDI_AMD_NNETBIN_POSTERIOR_DOWNLOAD_H_
 #include <algorithm>
@@ -35,9 +39,9 @@ class PosteriorWriter {
       CU_SAFE_CALL(hipK_event_create(&s.computed));
       CU_SAFE_CALL(hipK_event_create(&s.copied));
       void *p = NULL;
-      CU_SAFE_CALL(hipK_malloc(&p, 256));
+      CU_SAFE_CALL(hipK_malloc(&p, kMaxPieces * 4 * sizeof(int32_t)));
       s.dev_counts = static_cast<int32_t *>(p);
-      CU_SAFE_CALL(hipK_malloc_host(&p, 256));
+      CU_SAFE_CALL(hipK_malloc_host(&p, kMaxPieces * 4 * sizeof(int32_t)));
       s.host_counts = static_cast<int32_t *>(p);
       free_.push_back(&s);
     }
@@ -63,11 +67,26 @@ class PosteriorWriter {
     if (stream_) hipK_stream_destroy(stream_);
   }
 
+  static const int kMaxPieces = 256;  // utterances per slot
+
   /// A rows x cols device matrix to compute the next utterance's output into, with the row pitch of any
   /// other CuMatrix of that width; waits for a free slot.  Write into it as it is: a Resize to another shape
   /// would let go of the slot's memory.
   CuMatrix<BaseFloat> *Begin(int32 rows, int32 cols) {
-    KALDI_ASSERT(cur_ == NULL && rows >= 0 && cols >= 0);
+    BeginBatch();
+    return Finish(rows, cols);
+  }
+  /// The main stream's work queued so far fills the matrix Begin handed out, from `input` (the features
+  /// it was computed from; may be empty).  Queues the scans and the copy behind it and returns.
+  void Submit(const std::string &key, const CuMatrix<BaseFloat> &input) {
+    KALDI_ASSERT(cur_ != NULL && cur_->pieces.empty());
+    AddPiece(key, input, cur_->rows);
+    SubmitBatch();
+  }
+
+  /// Takes a free slot (waits for one) for a batch of utterances; follow with AddPiece ..., Finish, SubmitBatch.
+  void BeginBatch() {
+    KALDI_ASSERT(cur_ == NULL);
     Slot *s;
     {
       std::unique_lock<std::mutex> l(mu_);
@@ -76,6 +95,30 @@ class PosteriorWriter {
       s = free_.front();  // oldest first: its memory has been idle the longest
       free_.pop_front();
     }
+    s->pieces.clear();
+    s->rows = s->cols = s->stride = 0;
+    cur_ = s;
+  }
+  bool BatchOpen() const { return cur_ != NULL; }
+  int32 BatchPieces() const { return cur_ ? static_cast<int32>(cur_->pieces.size()) : 0; }
+  /// The next `rows` rows of the batch belong to `key`; `input` are the features they will be computed from (may
+  /// be empty): their NaN / inf count is queued on the main stream now, while they are where the caller has them.
+  void AddPiece(const std::string &key, const CuMatrix<BaseFloat> &input, int32 rows) {
+    KALDI_ASSERT(cur_ != NULL && static_cast<int32>(cur_->pieces.size()) < kMaxPieces && rows >= 0);
+    Slot *s = cur_;
+    Piece pc;
+    pc.key = key;
+    pc.row0 = s->pieces.empty() ? 0 : s->pieces.back().row0 + s->pieces.back().rows;
+    pc.rows = rows;
+    CU_SAFE_CALL(hipF_count_nonfinite(CuDevice::Instantiate().MainStream(), input.Data(), input.Dim(),
+                                      s->dev_counts + 4 * s->pieces.size()));
+    s->pieces.push_back(pc);
+  }
+  /// Sizes the slot's matrix for the whole batch (rows = the sum of the pieces' rows, unless none was added yet)
+  /// and hands it out to compute into.
+  CuMatrix<BaseFloat> *Finish(int32 rows, int32 cols) {
+    KALDI_ASSERT(cur_ != NULL && rows >= 0 && cols >= 0);
+    Slot *s = cur_;
     s->rows = rows;
     s->cols = cols;
     s->stride = static_cast<int32>(((static_cast<size_t>(cols) * sizeof(BaseFloat) + 255) & ~static_cast<size_t>(255)) / sizeof(BaseFloat));
@@ -99,25 +142,26 @@ class PosteriorWriter {
       s->host = static_cast<BaseFloat *>(p);
     }
     s->view.AttachView(s->dev, rows, cols, s->stride);
-    cur_ = s;
     return &s->view;
   }
-
-  /// The main stream's work queued so far fills the matrix Begin handed out, from `input` (the features
-  /// it was computed from; may be empty).  Queues the scans and the copy behind it and returns.
-  void Submit(const std::string &key, const CuMatrix<BaseFloat> &input) {
-    KALDI_ASSERT(cur_ != NULL);
+  /// The main stream's work queued so far fills the batch's matrix.  Queues every piece's output scan and one
+  /// copy of the whole matrix behind it and returns.
+  void SubmitBatch() {
+    KALDI_ASSERT(cur_ != NULL && !cur_->pieces.empty());
     Slot *s = cur_;
     cur_ = NULL;
-    s->key = key;
+    KALDI_ASSERT(s->pieces.back().row0 + s->pieces.back().rows == s->rows);
     CuDevice &dev = CuDevice::Instantiate();
     khStream_t main = dev.MainStream();
-    CU_SAFE_CALL(hipF_count_nonfinite(main, input.Data(), input.Dim(), s->dev_counts));
-    ::MatrixDim d = {s->rows, s->cols, s->stride};
-    CU_SAFE_CALL(hipF_count_nonfinite(main, s->dev, d, s->dev_counts + 2));
+    for (size_t i = 0; i < s->pieces.size(); ++i) {
+      ::MatrixDim d = {s->pieces[i].rows, s->cols, s->stride};
+      CU_SAFE_CALL(hipF_count_nonfinite(main, s->dev + static_cast<size_t>(s->pieces[i].row0) * s->stride, d,
+                                        s->dev_counts + 4 * i + 2));
+    }
     CU_SAFE_CALL(hipK_event_record(s->computed, main));
     CU_SAFE_CALL(hipK_stream_wait_event(stream_, s->computed));
-    CU_SAFE_CALL(hipK_memcpy_2d_async(stream_, s->host_counts, 16, s->dev_counts, 16, 16, 1, 1));
+    const size_t cbytes = s->pieces.size() * 4 * sizeof(int32_t);
+    CU_SAFE_CALL(hipK_memcpy_2d_async(stream_, s->host_counts, cbytes, s->dev_counts, cbytes, cbytes, 1, 1));
     const size_t pitch = s->stride * sizeof(BaseFloat);
     CU_SAFE_CALL(hipK_memcpy_2d_async(stream_, s->host, pitch, s->dev, pitch, pitch, s->rows, 1));
     CU_SAFE_CALL(hipK_event_record(s->copied, stream_));
@@ -144,13 +188,17 @@ class PosteriorWriter {
   }
 
  private:
+  struct Piece {  // one utterance of a slot's matrix
+    std::string key;
+    int32 row0, rows;
+  };
   struct Slot {
     BaseFloat *dev = NULL, *host = NULL;
     size_t dev_cap = 0, host_cap = 0;
-    int32_t *dev_counts = NULL, *host_counts = NULL;  // NaN, +inf of the input; NaN, +inf of the output
+    int32_t *dev_counts = NULL, *host_counts = NULL;  // per piece: NaN, +inf of the input; NaN, +inf of the output
     khEvent_t computed = NULL, copied = NULL;
     int32 rows = 0, cols = 0, stride = 0;
-    std::string key;
+    std::vector<Piece> pieces;
     CuMatrix<BaseFloat> view;
   };
   static size_t Headroom(size_t bytes) { return std::max<size_t>(bytes + bytes / 4, static_cast<size_t>(16) << 20); }
@@ -163,18 +211,22 @@ class PosteriorWriter {
   }
   void WriteOne(Slot *s) {
     CU_SAFE_CALL(hipK_event_synchronize(s->copied));
-    // the reference's messages, features first (nnetbin/nnet-forward.cc:116-123, 147-156)
-    if (s->host_counts[0]) KALDI_ERR << "NaN in features of : " << s->key;
-    if (s->host_counts[1]) KALDI_ERR << "inf in features of : " << s->key;
-    if (s->host_counts[2]) KALDI_ERR << "NaN in NNet output of : " << s->key;
-    if (s->host_counts[3]) KALDI_ERR << "inf in NNet output of : " << s->key;
-    const BaseFloat *data = s->host;
-    const int32 rows = s->rows, cols = s->cols, stride = s->stride;
-    writer_.WriteWith(s->key, [data, rows, cols, stride](std::ostream &os, bool binary) {
-      InitKaldiOutputStream(os, binary);
-      Matrix<BaseFloat>::WriteData(os, binary, data, rows, cols, stride);
-      return os.good();
-    });
+    for (size_t i = 0; i < s->pieces.size(); ++i) {
+      const Piece &pc = s->pieces[i];
+      const int32_t *cnt = s->host_counts + 4 * i;
+      // the reference's messages, features first (nnetbin/nnet-forward.cc:116-123, 147-156)
+      if (cnt[0]) KALDI_ERR << "NaN in features of : " << pc.key;
+      if (cnt[1]) KALDI_ERR << "inf in features of : " << pc.key;
+      if (cnt[2]) KALDI_ERR << "NaN in NNet output of : " << pc.key;
+      if (cnt[3]) KALDI_ERR << "inf in NNet output of : " << pc.key;
+      const int32 rows = pc.rows, cols = s->cols, stride = s->stride;
+      const BaseFloat *data = s->host + static_cast<size_t>(pc.row0) * stride;
+      writer_.WriteWith(pc.key, [data, rows, cols, stride](std::ostream &os, bool binary) {
+        InitKaldiOutputStream(os, binary);
+        Matrix<BaseFloat>::WriteData(os, binary, data, rows, cols, stride);
+        return os.good();
+      });
+    }
   }
   void Run() {
     for (;;) {

@@ -230,9 +230,10 @@ def test_forward_tool_matches_reference(hip, nn, tmp_path):
 
 
 def test_forward_tool_pipeline_ragged_utterances(hip, nn, tmp_path):
-    """nnet-forward keeps several utterances in flight (upload, kernels, download, write): 40 utterances of 1..900
-    frames, more than it has buffers, widths that are and are not a multiple of 4, against the numpy oracle; and
-    the same utterances in the opposite order give the same bits per utterance.  A network whose output
+    """nnet-forward keeps several utterances in flight (upload, kernels, download, write) and runs several of them
+    per pass through the network: 40 utterances of 1..900 frames, more than it has buffers, widths that are and are
+    not a multiple of 4, against the numpy oracle; the same utterances in the opposite order (so in other batches)
+    give the same bits per utterance, and so does any batch size.  A network whose output
     overflows is reported as the reference reports it (nnetbin/nnet-forward.cc:147-156)."""
     rs = np.random.RandomState(91)
     for out_dim in (52, 50):
@@ -257,6 +258,19 @@ def test_forward_tool_pipeline_ragged_utterances(hip, nn, tmp_path):
             assert m.shape == (x.shape[0], out_dim)
             np.testing.assert_allclose(m, net.feedforward(x), rtol=1e-4, atol=2e-6)
             assert np.array_equal(m, got_b[k])
+        # Batching (several utterances per pass through the network, --batch-frames, default 4096): batches of
+        # ~300 frames (utterances longer than a batch, many flushes) and one batch for everything give the bits
+        # of the default; one utterance at a time (0) may pick other GEMM plans and agrees to rounding.
+        for bf, exact in ((300, True), (1000000, True), (0, False)):
+            run_tool(nn, "nnet-forward", ["--silent=true", "--batch-frames=%d" % bf, str(tmp_path / "m.nnet"),
+                                          "ark:" + str(tmp_path / "a.ark"), "ark:" + str(tmp_path / "oc.ark")])
+            got_c = O.read_matrix_ark((tmp_path / "oc.ark").read_bytes())
+            assert [k for k, _ in got_c] == [k for k, _ in utts]
+            for (k, m), (_, c) in zip(got_a, got_c):
+                if exact:
+                    assert np.array_equal(m, c), (bf, k)
+                else:
+                    np.testing.assert_allclose(c, m, rtol=1e-5, atol=1e-7)
     # a linear output that overflows to +inf
     big = [O.BiasedLinearity(np.full((8, 40), 3e38, f32), np.zeros(8, f32))]
     (tmp_path / "big.nnet").write_bytes(O.write_nnet(big, True))
