@@ -91,7 +91,9 @@ Plan make_plan(int M, int N, int K, int num_cu, bool allow_split, bool always_sl
   for (int c = 0; c < ncfg; ++c) {
     const TileCfg &t = kCfgs[c];
     if (t.wk > 1 && (!allow_wk || row_invariant)) continue;
-    if (force_bm > 0 ? (t.bm != force_bm || t.bn != force_bn) : !(c == 0 || (t.wk > 1 && wk_on))) continue;
+    // (row-invariant plans, i.e. batched forward passes with thousands of rows: the 64x128 tile competes too)
+    if (force_bm > 0 ? (t.bm != force_bm || t.bn != force_bn) : !(c == 0 || (t.wk > 1 && wk_on) || (row_invariant && c == 2)))
+      continue;
     const int bkt = kBK * t.wk;
     const int ktiles = (K + bkt - 1) / bkt;
     const int tm = (M + t.bm - 1) / t.bm, tn = (N + t.bn - 1) / t.bn;
@@ -123,6 +125,13 @@ Plan make_plan(int M, int N, int K, int num_cu, bool allow_split, bool always_sl
                                                                                  : floor(512.0 / t.vgprs);
       const double rounds = n / (co > 1.0 ? co : 1.0);
       double cost = (n * per_block * share + (rounds > 1.0 ? rounds : 1.0) * t.fixed) / cyc_per_us;
+      if (row_invariant && kmajor_whole_tile && force_bm <= 0) {
+        // Many rows, K unsplit: whole rounds of co-resident workgroups -- three per CU for the 64x64 kernel with
+        // whole-tile fragments (152 registers), two for 64x128 -- each round as long as its workgroups' MFMAs
+        // together.  (Sweep at 4096 rows: 2048-wide layer 64x64 270 us, 64x128 250; 9000-wide 1231 / 1103.)
+        const double co_ri = c == 0 ? 3.0 : 2.0;
+        cost = (ceil(blocks / (co_ri * num_cu)) * co_ri * mfma + t.fixed) / cyc_per_us + blocks * 1e-4;
+      }
       if (s > 1 || always_slabs) cost += (s + 1.0) * (double)M * N * 4.0 / 3.5e6 + 2.5;
       // every doubling of the split doubles the workgroups that pay a prologue and an epilogue, which the fixed
       // term above undercounts for short K ranges (sweep of the 256 x 9000 x 2048 product: 64x64 split 4 measures
