@@ -32,8 +32,8 @@ sys.path.insert(0, ROOT)
 
 F32_MFMA_PEAK_TFLOPS = 157.3   # MI355X dense fp32 matrix peak (256 CU x 4 SIMD x 64 FLOP/clk x 2.4 GHz)
 WORKLOADS = {
-    # kind "train": one bunch of nnet-train-xent-hardlab-frmshuff; "forward": one utterance of nnet-forward
-    # (Nnet::Feedforward, utterances of 300..1200 frames); "rbm": one bunch of rbm-train-cd1-frmshuff
+    # kind "train": one bunch of nnet-train-xent-hardlab-frmshuff; "forward": one batch of nnet-forward
+    # (Nnet::Feedforward on utterances of 300..1200 frames gathered to >= 4096); "rbm": one bunch of rbm-train-cd1-frmshuff
     "swbd": dict(kind="train", dims=[1320] + [2048] * 7 + [9000], name="swbd-1320-7x2048-9000-xent-train"),
     "rm": dict(kind="train", dims=[440, 1024, 1024, 1024, 1024, 1483], name="rm-440-4x1024-1483-xent-train"),
     "swbd-forward": dict(kind="forward", dims=[1320] + [2048] * 7 + [9000], name="swbd-1320-7x2048-9000-forward"),
@@ -211,14 +211,26 @@ def main():
 
     rs = np.random.RandomState(100 + rank)
     if kind == "forward":
-        # utterance-sharded inference: every rank works through its own utterances, no collective
+        # utterance-sharded inference: every rank works through its own utterances, no collective.  As the tool
+        # does (nnet-forward --batch-frames=4096): utterances gathered until a batch holds 4096 frames or more, one
+        # pass through the network per batch, GEMM plans that keep a row's bits independent of its batch.
         trainer = nn.Trainer(model_path)
-        lens = np.random.RandomState(777 + rank).randint(300, 1201, 16)
-        if os.environ.get("KALDI_BENCH_UTT_ROWS"):   # (probe: every "utterance" this many rows, e.g. a batch of utterances)
-            lens[:] = int(os.environ["KALDI_BENCH_UTT_ROWS"])
-        utts = [h.DevMatrix.from_numpy(rs.standard_normal((int(n), dims[0])).astype(np.float32)) for n in lens]
-        post = h.DevMatrix(int(lens.max()), dims[-1])
-        frames_of = lambda i: int(lens[i % len(utts)])
+        h.call("hipK_gemm_row_invariant", 1)
+        lens = np.random.RandomState(777 + rank).randint(300, 1201, 64)
+        if os.environ.get("KALDI_BENCH_UTT_ROWS"):   # (probe: one "utterance" of this many rows per pass, free plans)
+            lens = np.full(16, int(os.environ["KALDI_BENCH_UTT_ROWS"]))
+            h.call("hipK_gemm_row_invariant", 0)
+            batch_rows = [int(n) for n in lens]
+        else:
+            batch_rows, cur = [], 0
+            for n in lens:
+                cur += int(n)
+                if cur >= 4096:
+                    batch_rows.append(cur)
+                    cur = 0
+        utts = [h.DevMatrix.from_numpy(rs.standard_normal((n, dims[0])).astype(np.float32)) for n in batch_rows]
+        post = h.DevMatrix(max(batch_rows), dims[-1])
+        frames_of = lambda i: batch_rows[i % len(utts)]
 
         def step(i):
             trainer.feedforward(utts[i % len(utts)], post)
