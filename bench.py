@@ -45,7 +45,7 @@ WORKLOADS = {
 }
 METRICS = {"train": "DNN train frames/sec (fwd+bwd+update)", "forward": "DNN forward frames/sec (nnet-forward)",
            "rbm": "RBM CD-1 frames/sec"}
-BUNCH = 256
+BUNCH = int(os.environ.get("KALDI_BENCH_BUNCH", "256"))  # (the variable: probes at other bunch sizes; the benchmark is 256)
 
 
 def flops_per_frame(dims, kind="train"):
