@@ -186,7 +186,8 @@ void Nnet::Backpropagate(const CuMatrix<BaseFloat> &in_err, CuMatrix<BaseFloat> 
     if (!overlap || !nnet_[i]->IsUpdatable()) return;
     if (nnet_[i]->GetType() != Component::kBiasedLinearity) return;
     BiasedLinearity *bl = static_cast<BiasedLinearity *>(nnet_[i]);
-    bl->SetDoubleBuffer(dp_ranks_ == 1 || dp_gather_);
+    // (gather exchange with grouped updates: the one update launch runs behind the whole pass, in place)
+    bl->SetDoubleBuffer((dp_ranks_ == 1 || dp_gather_) && !(dp_ranks_ > 1 && dp_gather_ && group_updates_));
     if (dp_ranks_ > 1) {
       // data-parallel: only the mark in the main stream; whoever needs it waits for it when its work is queued
       if (layer_events_[i] == NULL) CU_SAFE_CALL(hipK_event_create_ordering(&layer_events_[i]));
@@ -253,6 +254,17 @@ void Nnet::Backpropagate(const CuMatrix<BaseFloat> &in_err, CuMatrix<BaseFloat> 
                                   static_cast<size_t>(rows) * dp_in_all_[i].Stride()));
       CU_SAFE_CALL(hipF_allgather(dev.AuxStream(), err.Data(), dp_err_all_[i].Data(),
                                   static_cast<size_t>(rows) * err.Stride()));
+      {
+        // the updates of all layers as ONE launch on the gathered rows, behind the pass (below), where the
+        // layer's update is the single fused launch
+        khAffineUpdate item;
+        if (group_updates_ && bl->DescribeUpdate(dp_in_all_[i], dp_err_all_[i], &item)) {
+          deferred_updates_.push_back(item);
+          deferred_layers_.push_back(i);
+          aux_used = true;
+          return;
+        }
+      }
       dev.Order(dev.AuxStream(), dev.SideStream(), &grad_events_[i]);
       // without a second weight buffer (L1 penalty) the step must also wait for this layer's back-propagation
       if (!bl->UpdateKeepsOldWeights()) CU_SAFE_CALL(hipK_stream_wait_event(dev.SideStream(), read_events_[i]));
@@ -388,6 +400,8 @@ void Nnet::Backpropagate(const CuMatrix<BaseFloat> &in_err, CuMatrix<BaseFloat> 
   }
   for (size_t k = 0; k < pending.size(); ++k) update(pending[k].i, *pending[k].input, *pending[k].err);
   if (!deferred_updates_.empty()) {
+    // (data-parallel gather exchange: the rows of every rank have to be in first)
+    if (dp_ranks_ > 1) dev.Order(dev.AuxStream(), dev.MainStream(), &aux_join_event_);
     CuProfileScope p("BiasedLinearity::Update");
     CU_SAFE_CALL(hipF_affine_update_group(dev.Stream(), static_cast<int32>(deferred_updates_.size()), &deferred_updates_[0]));
     for (size_t k = 0; k < deferred_layers_.size(); ++k)
