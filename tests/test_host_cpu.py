@@ -25,6 +25,27 @@ def test_device_library_exports_every_declared_symbol():
     assert "hipI32_set_const" in h.PROTOS
 
 
+def test_public_header_is_plain_c_and_struct_layouts_match_the_binding(tmp_path):
+    """include/kaldi_hip.h compiles as C (the boundary a foreign-function binding sees), and the structs that cross
+    it by value or by array -- MatrixDim, khAffineUpdate -- have the size and field offsets the ctypes mirror in
+    kaldi_amd/hip.py assumes."""
+    import kaldi_amd.hip as h
+    fields = [f for f, _ in h.AffineUpdate._fields_]
+    cname = {"in_": "in"}
+    src = tmp_path / "layout.c"
+    src.write_text(
+        '#include <stddef.h>\n#include <stdio.h>\n#include "kaldi_hip.h"\nint main(void) {\n'
+        '  printf("%zu %zu\\n", sizeof(MatrixDim), sizeof(khAffineUpdate));\n' +
+        "".join('  printf("%%zu\\n", offsetof(khAffineUpdate, %s));\n' % cname.get(f, f) for f in fields) +
+        "  return 0;\n}\n")
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()
+    assert int(out[0]) == ctypes.sizeof(h.MatrixDim) and int(out[1]) == ctypes.sizeof(h.AffineUpdate)
+    for f, off in zip(fields, out[2:]):
+        assert int(off) == getattr(h.AffineUpdate, f).offset, f
+
+
 def test_host_library_exports_capi():
     hdr = open(os.path.join(ROOT, "kaldi_amd", "csrc", "capi", "nnet1_capi.h")).read()
     names = re.findall(r"\b((?:nnet1|rbm1)_\w+)\s*\(", hdr)
