@@ -73,13 +73,9 @@ class CuDevice {
     if (copy_stream_ == NULL) CU_SAFE_CALL(hipK_stream_create(&copy_stream_));
     return copy_stream_;
   }
-  static bool kOrderingEvents() {
-    static const bool on = getenv("KALDI_AMD_TIMED_ORDER_EVENTS") == NULL;  // (the variable: for A/B measurements)
-    return on;
-  }
   /// `waiter` continues only after everything queued on `done` so far has finished (no host wait).
   void Order(khStream_t done, khStream_t waiter, khEvent_t *ev) {
-    if (*ev == NULL) CU_SAFE_CALL(kOrderingEvents() ? hipK_event_create_ordering(ev) : hipK_event_create(ev));
+    if (*ev == NULL) CU_SAFE_CALL(hipK_event_create_ordering(ev));
     CU_SAFE_CALL(hipK_event_record(*ev, done));
     CU_SAFE_CALL(hipK_stream_wait_event(waiter, *ev));
   }

@@ -68,7 +68,6 @@ struct Plan {
 // in-kernel stamps) hides behind the K loops of the workgroups that share the CU, so it is exposed
 // once per round of co-resident workgroups; a split K adds the slab round trip and the launch of
 // the kernel that sums the slabs.
-const bool old_staging_term = getenv("KALDI_HIP_PLAN_OLD_STAGING") != nullptr;  // for A/B measurements
 int force_bm = -1, force_bn = -1, force_s = -1;
 // hipK_gemm_row_invariant: only plans that sum a row's K range in one piece (no split over workgroups or waves), so
 // that a row's result does not depend on how many other rows share the call
@@ -217,7 +216,7 @@ int run_gemm(khStream_t s, bool a_kmajor, bool b_kmajor, GemmParams p, bool allo
   const bool vec = kh::aligned16(p.A) && kh::aligned16(p.B) && (p.lda % 4 == 0) && (p.ldb % 4 == 0);
   Plan plan = make_plan(p.M, p.N, p.K, kh::ctx().num_cu > 0 ? kh::ctx().num_cu : 256, allow_split || softmax,
                         softmax, EPI != EPI_UPDATE && EPI != EPI_RBM,
-                        a_kmajor && b_kmajor && EPI != EPI_UPDATE && EPI != EPI_RBM && KH_SCHED >= 2 && !old_staging_term);
+                        a_kmajor && b_kmajor && EPI != EPI_UPDATE && EPI != EPI_RBM && KH_SCHED >= 2);
   apply_plan(p, plan, a_kmajor, b_kmajor);
   const double flops = 2.0 * p.M * p.N * p.K;
   if (p.splitk == 1 && !softmax) {
@@ -747,8 +746,7 @@ KH_EXPORT int hipF_affine_update_group(khStream_t s, int32_t count, const khAffi
     Plan plan = {big ? 3 : 0, 1, ((p.K + kBK - 1) / kBK) * kBK};  // 128 x 128 or 64 x 64 tiles, K whole
     apply_plan(p, plan, false, false);
     // an XCD's run of tiles: leave the operand with more tiles sliced (the 9000-output layer: the error matrix)
-    static const bool rows_first = getenv("KALDI_HIP_GROUP_ROWS_FIRST") != nullptr;  // for A/B measurements
-    p.n_fastest = (!rows_first && p.tiles_m > 2 * p.tiles_n) ? 1 : 0;
+    p.n_fastest = p.tiles_m > 2 * p.tiles_n ? 1 : 0;
     if (off || !vec || p.a_bytes == 0 || force_bm > 0) {
       // not for the grouped kernel: on its own, in order
       int rc = flush();
