@@ -326,8 +326,8 @@ __global__ __launch_bounds__(1024) void rbm_bias_kernel(const float *pos, int ld
       tp += pp[i][lane];
       tn += pn[i][lane];
     }
-    float d = -g * tn + mom * dbias[c];
-    d = g * tp + d;
+    float d = kh::mul_add(mom, dbias[c], -g * tn);
+    d = kh::mul_add(g, tp, d);
     dbias[c] = d;
     bias[c] = d + bias[c];
   }
@@ -383,8 +383,8 @@ __global__ __launch_bounds__(256) void rbm_bias_vec_kernel(RbmBiasArgs vis, RbmB
       tp += fp[i * 64 + threadIdx.x];
       tn += fn[i * 64 + threadIdx.x];
     }
-    float d = -g * tn + mom * a.dbias[c];
-    d = g * tp + d;
+    float d = kh::mul_add(mom, a.dbias[c], -g * tn);
+    d = kh::mul_add(g, tp, d);
     a.dbias[c] = d;
     a.bias[c] = d + a.bias[c];
   }
@@ -793,10 +793,16 @@ KH_EXPORT int hipF_affine_update(khStream_t s, int32_t N, int32_t O, int32_t I, 
                                   bcorr);
 }
 
-KH_EXPORT int hipF_rbm_update_weights(khStream_t s, int32_t N, int32_t H, int32_t V, const float *pos_vis, int32_t ldpv,
-                                      const float *pos_hid, int32_t ldph, const float *neg_vis, int32_t ldnv,
-                                      const float *neg_hid, int32_t ldnh, float lr, float momentum, float l2, float *W,
-                                      int32_t ldw, float *dW, int32_t lddw) {
+namespace {
+// Vectors of the bias half, for the launch that can carry it (rbm_update_weights sets `done` when it did).
+struct RbmBiasVectors {
+  float *vis_bias, *dvis_bias, *hid_bias, *dhid_bias;
+  bool done;
+};
+int rbm_update_weights(khStream_t s, int32_t N, int32_t H, int32_t V, const float *pos_vis, int32_t ldpv,
+                       const float *pos_hid, int32_t ldph, const float *neg_vis, int32_t ldnv, const float *neg_hid,
+                       int32_t ldnh, float lr, float momentum, float l2, float *W, int32_t ldw, float *dW, int32_t lddw,
+                       RbmBiasVectors *bv) {
   KH_CHECK_INIT();
   KH_REQUIRE(N > 0 && H > 0 && V > 0);
   KH_REQUIRE(pos_vis && pos_hid && neg_vis && neg_hid && W && dW);
@@ -828,6 +834,15 @@ KH_EXPORT int hipF_rbm_update_weights(khStream_t s, int32_t N, int32_t H, int32_
       p.nk1 = N / kBK;
       p.K = 2 * N;
       p.k_per_split = 2 * N;
+      if (bv && H % 4 == 0 && V % 4 == 0) {
+        // both bias statistics by workgroups at the end of this launch (rbm_bias_tile): no launch of their own
+        p.bias_io = bv->hid_bias;
+        p.bcorr = bv->dhid_bias;
+        p.bias2_io = bv->vis_bias;
+        p.bcorr2 = bv->dvis_bias;
+        p.bias_tiles = (H + 63) / 64 + (V + 63) / 64;
+        bv->done = true;
+      }
       hipStream_t st = kh::pick(s);
       TimedLaunch tl(st, 4.0 * H * V * N);
       launch_layout<EPI_RBM>(st, p, 0, true, false, false);
@@ -849,6 +864,15 @@ KH_EXPORT int hipF_rbm_update_weights(khStream_t s, int32_t N, int32_t H, int32_
   p2.Wout = W;
   p2.ldwout = ldw;
   return run_gemm<EPI_RBM>(s, false, false, p2, false);
+}
+}  // namespace
+
+KH_EXPORT int hipF_rbm_update_weights(khStream_t s, int32_t N, int32_t H, int32_t V, const float *pos_vis, int32_t ldpv,
+                                      const float *pos_hid, int32_t ldph, const float *neg_vis, int32_t ldnv,
+                                      const float *neg_hid, int32_t ldnh, float lr, float momentum, float l2, float *W,
+                                      int32_t ldw, float *dW, int32_t lddw) {
+  return rbm_update_weights(s, N, H, V, pos_vis, ldpv, pos_hid, ldph, neg_vis, ldnv, neg_hid, ldnh, lr, momentum, l2, W, ldw,
+                            dW, lddw, nullptr);
 }
 
 KH_EXPORT int hipF_rbm_update_bias(khStream_t s, int32_t N, int32_t H, int32_t V, const float *pos_vis, int32_t ldpv,
@@ -881,9 +905,12 @@ KH_EXPORT int hipF_rbm_update(khStream_t s, int32_t N, int32_t H, int32_t V, con
                               const float *neg_hid, int32_t ldnh, float lr, float momentum, float l2, float *W,
                               int32_t ldw, float *dW, int32_t lddw, float *vis_bias, float *dvis_bias,
                               float *hid_bias, float *dhid_bias) {
-  int rc = hipF_rbm_update_weights(s, N, H, V, pos_vis, ldpv, pos_hid, ldph, neg_vis, ldnv, neg_hid, ldnh, lr, momentum, l2,
-                                   W, ldw, dW, lddw);
-  if (rc != KH_OK) return rc;
+  KH_REQUIRE(vis_bias && dvis_bias && hid_bias && dhid_bias);
+  static const bool own_launch = getenv("KALDI_HIP_RBM_BIAS_LAUNCH") != nullptr;  // for A/B measurements
+  RbmBiasVectors bv = {vis_bias, dvis_bias, hid_bias, dhid_bias, false};
+  int rc = rbm_update_weights(s, N, H, V, pos_vis, ldpv, pos_hid, ldph, neg_vis, ldnv, neg_hid, ldnh, lr, momentum, l2, W, ldw,
+                              dW, lddw, own_launch ? nullptr : &bv);
+  if (rc != KH_OK || bv.done) return rc;
   return hipF_rbm_update_bias(s, N, H, V, pos_vis, ldpv, pos_hid, ldph, neg_vis, ldnv, neg_hid, ldnh, lr, momentum, vis_bias,
                               dvis_bias, hid_bias, dhid_bias);
 }

@@ -65,6 +65,11 @@ struct GemmParams {
   float *bias_io;
   float *bcorr;
   int bias_tiles;
+  // EPI_RBM with two products, bias_tiles > 0: both bias statistics of the CD-1 step by workgroups at the end of the
+  // launch, ceil(M / 64) for the hidden units (columns of A / A2; bias_io, bcorr = hidden bias and its momentum
+  // term) and ceil(N / 64) for the visible ones (columns of B / B2; bias2_io, bcorr2)
+  float *bias2_io;
+  float *bcorr2;
 #ifdef KH_GEMM_STAMPS
   unsigned long long *stamps;
 #endif
@@ -1026,6 +1031,60 @@ __device__ __forceinline__ void bias_update_tile(const GemmParams &p, float *lds
   KH_RT(13);
 }
 
+// Bias statistics of an RBM CD-1 step for 64 units, by one 256-thread workgroup at the end of the two-product
+// weight launch (GemmParams::bias2_io): d = -g * colsum(neg) + mom * dbias ; d = g * colsum(pos) + d ; dbias = d ;
+// bias += d.  Thread (grp = tid / 16, quad = tid % 16) sums rows grp, grp + 16, ... of 4 adjacent columns of the
+// negative and of the positive matrix, 2 x 16 loads of 16 bytes in flight per 256 rows, added in row order; the 16
+// partial sums are combined in the order 0..15 -- the sums of the stand-alone bias kernels, bit for bit.
+__device__ __forceinline__ void rbm_bias_tile(const GemmParams &p, float *lds, int tile) {
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  const int nh = (p.M + 63) >> 6;
+  const bool hid = tile < nh;
+  if (!hid) tile -= nh;
+  const float *neg = hid ? p.A : p.B, *pos = hid ? p.A2 : p.B2;
+  const int ld = hid ? p.lda : p.ldb, D = hid ? p.M : p.N, N = p.nk1 * kBK;
+  float *bias = hid ? p.bias_io : p.bias2_io, *dbias = hid ? p.bcorr : p.bcorr2;
+  const int grp = threadIdx.x >> 4, quad = threadIdx.x & 15;
+  const int c0 = tile * 64 + quad * 4;
+  v4f ap = {0.f, 0.f, 0.f, 0.f}, an = {0.f, 0.f, 0.f, 0.f};
+  if (c0 < D) {  // (D is a multiple of 4: whole quads)
+    for (int r0 = grp; r0 < N; r0 += 256) {
+      v4f xp[16], xn[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const int r = r0 + 16 * u;
+        const v4f z = {0.f, 0.f, 0.f, 0.f};
+        xp[u] = r < N ? *reinterpret_cast<const v4f *>(pos + (size_t)r * ld + c0) : z;
+        xn[u] = r < N ? *reinterpret_cast<const v4f *>(neg + (size_t)r * ld + c0) : z;
+      }
+#pragma unroll
+      for (int u = 0; u < 16; ++u)
+        if (r0 + 16 * u < N) {
+          ap += xp[u];
+          an += xn[u];
+        }
+    }
+  }
+  v4f *pp = reinterpret_cast<v4f *>(lds), *pn = pp + 256;
+  pp[grp * 16 + quad] = ap;
+  pn[grp * 16 + quad] = an;
+  __syncthreads();
+  const int c = tile * 64 + threadIdx.x;
+  if (threadIdx.x < 64 && c < D) {
+    const float *fp = lds, *fn = lds + 1024;
+    float tp = 0.f, tn = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      tp += fp[i * 64 + threadIdx.x];
+      tn += fn[i * 64 + threadIdx.x];
+    }
+    float d = kh::mul_add(p.beta, dbias[c], p.alpha * tn);  // (alpha = -g, alpha2 = g, beta = momentum)
+    d = kh::mul_add(p.alpha2, tp, d);
+    dbias[c] = d;
+    bias[c] = d + bias[c];
+  }
+}
+
 // One tile (64 or 128 rows) of a weight update, and the bias half of the update where this workgroup carries it.
 // The bias half rides in the update's launch: one workgroup of every tile row takes the column sums of the
 // error for its outputs first (the columns it is about to stream as its A operand), 64 at a time, and then
@@ -1079,6 +1138,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
     } else {
       gemm_tile<BM, BN, BK, WK, A_KMAJOR, B_KMAJOR, EPI, VEC>(p, lds, blockIdx.x, ntiles);
     }
+  } else if constexpr (EPI == EPI_RBM) {
+    static_assert(gemm_lds_floats<BM, BN, BK, WK, A_KMAJOR, B_KMAJOR>() >= 2048, "bias statistics need 2048 floats");
+    const int ntiles = p.tiles_m * p.tiles_n * p.splitk;
+    if ((int)blockIdx.x >= ntiles) rbm_bias_tile(p, lds, (int)blockIdx.x - ntiles);
+    else gemm_tile<BM, BN, BK, WK, A_KMAJOR, B_KMAJOR, EPI, VEC>(p, lds, blockIdx.x, ntiles);
   } else {
     gemm_tile<BM, BN, BK, WK, A_KMAJOR, B_KMAJOR, EPI, VEC>(p, lds, blockIdx.x, gridDim.x);
   }
@@ -1143,7 +1207,7 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(GemmParams p, const fl
 
 template <int BM, int BN, int WK, bool AK, bool BK_, int EPI>
 void launch_cfg(hipStream_t st, const GemmParams &p, bool vec) {
-  const int nblk = p.tiles_m * p.tiles_n * p.splitk + (EPI == EPI_UPDATE && BM != 64 ? p.bias_tiles : 0);
+  const int nblk = p.tiles_m * p.tiles_n * p.splitk + ((EPI == EPI_UPDATE && BM != 64) || EPI == EPI_RBM ? p.bias_tiles : 0);
   if (vec)
     hipLaunchKernelGGL((gemm_kernel<BM, BN, kBK, WK, AK, BK_, EPI, true>), dim3(nblk), dim3(256), p.dyn_lds, st, p);
   else

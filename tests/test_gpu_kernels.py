@@ -629,9 +629,20 @@ def test_rbm_cd1(hip, V, H, vt, ht):
         h.call("hipF_affine_forward", None, hact, h.TRANS, N, H, V, dnv.ptr, dnv.stride, dW.ptr, dW.stride, dhb.ptr,
                dnh.ptr, dnh.stride)
         np.testing.assert_allclose(dnh.numpy(), ref["neg_hid"], rtol=2e-5, atol=2e-5)
+        # (copies for the two-call form below: weights and bias statistics as launches of their own)
+        cW, cdW = dev(h, dW.numpy()), dev(h, ddW.numpy())
+        cvb, cdvb = dev(h, dvb.numpy()[0], False), dev(h, ddvb.numpy()[0], False)
+        chb, cdhb = dev(h, dhb.numpy()[0], False), dev(h, ddhb.numpy()[0], False)
         h.call("hipF_rbm_update", None, N, H, V, dpv.ptr, dpv.stride, dph.ptr, dph.stride, dnv.ptr, dnv.stride,
                dnh.ptr, dnh.stride, f32(0.01), f32(0.5), f32(2e-4), dW.ptr, dW.stride, ddW.ptr, ddW.stride, dvb.ptr,
                ddvb.ptr, dhb.ptr, ddhb.ptr)
+        # hipF_rbm_update carries the bias statistics in the weight launch where it can: same bits as the two calls
+        h.call("hipF_rbm_update_weights", None, N, H, V, dpv.ptr, dpv.stride, dph.ptr, dph.stride, dnv.ptr, dnv.stride,
+               dnh.ptr, dnh.stride, f32(0.01), f32(0.5), f32(2e-4), cW.ptr, cW.stride, cdW.ptr, cdW.stride)
+        h.call("hipF_rbm_update_bias", None, N, H, V, dpv.ptr, dpv.stride, dph.ptr, dph.stride, dnv.ptr, dnv.stride,
+               dnh.ptr, dnh.stride, f32(0.01), f32(0.5), cvb.ptr, cdvb.ptr, chb.ptr, cdhb.ptr)
+        for a, b in ((dW, cW), (ddW, cdW), (dvb, cvb), (ddvb, cdvb), (dhb, chb), (ddhb, cdhb)):
+            assert np.array_equal(a.numpy(), b.numpy())
         np.testing.assert_allclose(dW.numpy(), rbm.W, rtol=1e-4, atol=1e-6)
         np.testing.assert_allclose(ddW.numpy(), rbm.W_corr, rtol=1e-3, atol=1e-7)
         np.testing.assert_allclose(dvb.numpy()[0], rbm.vis_bias, rtol=1e-4, atol=1e-6)
