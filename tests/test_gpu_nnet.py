@@ -280,6 +280,46 @@ def test_forward_tool_pipeline_ragged_utterances(hip, nn, tmp_path):
     assert "inf in NNet output of : pos" in err
 
 
+def test_forward_tool_batches_behind_a_per_utterance_transform(hip, nn, tmp_path):
+    """--feature-transform with a splice (<expand>, clamped at each utterance's own edges, nnet/nnet-various.h:35-80)
+    and a column selection (<copy>) runs per utterance; the network behind it takes several utterances per pass.
+    Against the oracle, and the same bits whatever the batch size; --apply-log and --class-frame-counts on top
+    (nnetbin/nnet-forward.cc:127-145)."""
+    rs = np.random.RandomState(93)
+    D = 12
+    offs = [-2, -1, 0, 1, 2]
+    keep = [i for i in range(D * len(offs)) if i % 5 != 3]   # 48 of 60 columns
+    transform = [O.Expand(D, D * len(offs), offs), O.Copy(D * len(offs), len(keep), keep)]
+    dims = [len(keep), 64, 36]
+    layers = []
+    for i in range(len(dims) - 1):
+        layers.append(O.BiasedLinearity((rs.randn(dims[i + 1], dims[i]) * 0.3).astype(f32), (rs.randn(dims[i + 1]) * 0.1).astype(f32)))
+        layers.append(O.Softmax(dims[i + 1]) if i == len(dims) - 2 else O.Sigmoid(dims[i + 1]))
+    (tmp_path / "t.nnet").write_bytes(O.write_nnet(transform, False))
+    (tmp_path / "m.nnet").write_bytes(O.write_nnet(layers, True))
+    lens = [1, 2, 3, 700] + [int(v) for v in rs.randint(1, 400, 20)]
+    utts = [("u%02d" % i, rs.randn(t, D).astype(f32)) for i, t in enumerate(lens)]
+    (tmp_path / "a.ark").write_bytes(O.write_matrix_ark(utts))
+    counts = rs.randint(1, 1000, dims[-1])
+    (tmp_path / "counts").write_text("[ " + " ".join(str(int(c)) for c in counts) + " ]\n")
+    net, tnet = O.Nnet(layers), O.Nnet(transform)
+    prior = np.log(counts.astype(f32) / f32(counts.sum())).astype(f32)
+    outs = {}
+    for bf in (4096, 300, 0):
+        run_tool(nn, "nnet-forward", ["--silent=true", "--batch-frames=%d" % bf, "--feature-transform=" + str(tmp_path / "t.nnet"),
+                                      "--apply-log=true", "--class-frame-counts=" + str(tmp_path / "counts"),
+                                      str(tmp_path / "m.nnet"), "ark:" + str(tmp_path / "a.ark"), "ark:" + str(tmp_path / "o.ark")])
+        outs[bf] = O.read_matrix_ark((tmp_path / "o.ark").read_bytes())
+        assert [k for k, _ in outs[bf]] == [k for k, _ in utts]
+    for (k, m), (_, x) in zip(outs[4096], utts):
+        want = np.log(net.feedforward(tnet.feedforward(x))) - prior
+        assert m.shape == want.shape
+        np.testing.assert_allclose(m, want, rtol=1e-4, atol=1e-5)
+    for (k, a), (_, b), (_, c) in zip(outs[4096], outs[300], outs[0]):
+        assert np.array_equal(a, b), k
+        np.testing.assert_allclose(c, a, rtol=1e-5, atol=5e-6)   # (log posterior - log prior: values near 0 cancel)
+
+
 @pytest.mark.parametrize("name,opts", [
     ("norand", ["--randomize=false"]),
     ("rand", []),
