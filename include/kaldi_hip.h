@@ -413,6 +413,18 @@ int hipF_rbm_update_bias(khStream_t s, int32_t N, int32_t H, int32_t V, const fl
                          const float *neg_hid, int32_t ldnh, float lr, float momentum, float *vis_bias,
                          float *dvis_bias, float *hid_bias, float *dhid_bias);
 
+/* hipF_rbm_update and the reconstruction error of the same step in one call -- the CD-1 loop's
+ * mse.Eval(neg_vis, pos_vis, ...) followed, after the second propagation, by rbm.RbmUpdate(...)
+ * (nnetbin/rbm-train-cd1-frmshuff.cc:139-150, nnet-loss.cc:160-194): additionally
+ *   mse_loss[0] += 0.5 * sum((neg_vis - pos_vis)^2)     (double on the device, as hipF_mse_eval; no diff matrix)
+ * The error only reads the two visible matrices, so where the weight launch carries the bias statistics it carries
+ * the error rows too (same bits as hipF_mse_eval); otherwise the error runs as hipF_mse_eval.  ldnv must equal ldpv. */
+int hipF_rbm_update_mse(khStream_t s, int32_t N, int32_t H, int32_t V, const float *pos_vis, int32_t ldpv,
+                        const float *pos_hid, int32_t ldph, const float *neg_vis, int32_t ldnv,
+                        const float *neg_hid, int32_t ldnh, float lr, float momentum, float l2, float *W,
+                        int32_t ldw, float *dW, int32_t lddw, float *vis_bias, float *dvis_bias,
+                        float *hid_bias, float *dhid_bias, double *mse_loss);
+
 /* ------------------------------------------------------------------------------------------
  * Multi-GPU (no counterpart in the reference, which is single-GPU: cu-device.cc).
  * One process per GPU; RCCL over xGMI.  The unique id is created on rank 0 and handed to the

@@ -26,7 +26,7 @@ struct RbmTrainer {
   Nnet nnet;
   CuRand<BaseFloat> cu_rand;
   MseProgress mse;
-  CuMatrix<BaseFloat> pos_vis, pos_hid, neg_vis, neg_hid, dummy;
+  CuMatrix<BaseFloat> pos_vis, pos_hid, neg_vis, neg_hid;
 };
 
 // device rows (ld) -> CuMatrix, the copy Cache::GetBunch makes
@@ -220,9 +220,9 @@ int rbm1_cd1_bunch(void *h, const float *feats_dev, int ld, int rows, int cols) 
     t->cu_rand.AddGaussNoise(&t->neg_hid);
   }
   rbm.Reconstruct(t->neg_hid, &t->neg_vis);
-  t->mse.Eval(t->neg_vis, t->pos_vis, &t->dummy);
   rbm.Propagate(t->neg_vis, &t->neg_hid);
-  rbm.RbmUpdate(t->pos_vis, t->pos_hid, t->neg_vis, t->neg_hid);
+  rbm.RbmUpdate(t->pos_vis, t->pos_hid, t->neg_vis, t->neg_hid, t->mse.DeviceLoss());  // (with the reconstruction error)
+  t->mse.Evaluated(t->neg_vis.NumRows());
   return 0;
   CAPI_CATCH(-1)
 }

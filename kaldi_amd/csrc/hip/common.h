@@ -139,6 +139,44 @@ __device__ __forceinline__ float block_max(float v, float *red) {
 // kernel that applies them gives the same bits.
 __device__ __forceinline__ float mul_add(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 
+// One row of Mse::Eval by one 256-thread workgroup, and the total by the workgroup that arrives last: diff = a - b
+// (stored when asked for), the row's sum of squares into row_sq[r]; the last of the `nrows` row workgroups to arrive
+// (a device-scope counter, back at zero afterwards) adds the rows up in double, in a fixed order, and adds half of
+// that to loss[0].  Row sums travel write-through / past the L1 (device-scope relaxed atomics), so no fence is needed.
+// Scratch: red[16] floats, sd[256] doubles, one unsigned, all in LDS.  Used by the stand-alone kernel and by the
+// row workgroups that ride in the RBM weight launch: the same bits from both.
+__device__ __forceinline__ void mse_row_and_total(const float *a_row, const float *b_row, float *diff_row, int cols,
+                                                  float *row_sq, int r, int nrows, unsigned *ticket, double *loss,
+                                                  float *red, double *sd, unsigned *arrived) {
+  float acc = 0.f;
+  for (int c = threadIdx.x; c < cols; c += 256) {
+    const float df = a_row[c] - b_row[c];
+    if (diff_row) diff_row[c] = df;
+    acc += df * df;
+  }
+  const float t = block_sum(acc, red);
+  if (threadIdx.x == 0) {
+    __hip_atomic_store(row_sq + r, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the row's sum has reached the L2
+    *arrived = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  if (*arrived != (unsigned)nrows - 1u) return;
+  double tot = 0.0;
+  for (int i = threadIdx.x; i < nrows; i += 256)
+    tot += (double)__hip_atomic_load(row_sq + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  sd[threadIdx.x] = tot;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) sd[threadIdx.x] += sd[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    loss[0] += 0.5 * sd[0];
+    __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
 // 1/(1+exp(-x)) in fp32.  expf() here is the correctly scaled library call (not the fast
 // intrinsic) so results stay within a few ulp of the reference's double evaluation.
 __device__ __forceinline__ float sigmoidf(float x) { return 1.0f / (1.0f + expf(-x)); }

@@ -798,6 +798,8 @@ namespace {
 struct RbmBiasVectors {
   float *vis_bias, *dvis_bias, *hid_bias, *dhid_bias;
   bool done;
+  double *mse_loss;  // not null: the reconstruction error rides along too (mse_done)
+  bool mse_done;
 };
 int rbm_update_weights(khStream_t s, int32_t N, int32_t H, int32_t V, const float *pos_vis, int32_t ldpv,
                        const float *pos_hid, int32_t ldph, const float *neg_vis, int32_t ldnv, const float *neg_hid,
@@ -844,6 +846,18 @@ int rbm_update_weights(khStream_t s, int32_t N, int32_t H, int32_t V, const floa
         bv->done = true;
       }
       hipStream_t st = kh::pick(s);
+      if (bv && bv->done && bv->mse_loss) {
+        // one more workgroup per row: the reconstruction error 1/2 * sum((neg_vis - pos_vis)^2), as hipF_mse_eval
+        void *ws;
+        int rc = kh::ensure_workspace(st, (size_t)N * 4, &ws);
+        if (rc != KH_OK) return rc;
+        rc = kh::stream_ticket(st, &p.mse_ticket);
+        if (rc != KH_OK) return rc;
+        p.mse_rows = N;
+        p.mse_row_sq = (float *)ws;
+        p.mse_loss = bv->mse_loss;
+        bv->mse_done = true;
+      }
       TimedLaunch tl(st, 4.0 * H * V * N);
       launch_layout<EPI_RBM>(st, p, 0, true, false, false);
       return kh::launch_status();
@@ -907,10 +921,38 @@ KH_EXPORT int hipF_rbm_update(khStream_t s, int32_t N, int32_t H, int32_t V, con
                               float *hid_bias, float *dhid_bias) {
   KH_REQUIRE(vis_bias && dvis_bias && hid_bias && dhid_bias);
   static const bool own_launch = getenv("KALDI_HIP_RBM_BIAS_LAUNCH") != nullptr;  // for A/B measurements
-  RbmBiasVectors bv = {vis_bias, dvis_bias, hid_bias, dhid_bias, false};
+  RbmBiasVectors bv = {vis_bias, dvis_bias, hid_bias, dhid_bias, false, nullptr, false};
   int rc = rbm_update_weights(s, N, H, V, pos_vis, ldpv, pos_hid, ldph, neg_vis, ldnv, neg_hid, ldnh, lr, momentum, l2, W, ldw,
                               dW, lddw, own_launch ? nullptr : &bv);
   if (rc != KH_OK || bv.done) return rc;
+  return hipF_rbm_update_bias(s, N, H, V, pos_vis, ldpv, pos_hid, ldph, neg_vis, ldnv, neg_hid, ldnh, lr, momentum, vis_bias,
+                              dvis_bias, hid_bias, dhid_bias);
+}
+
+KH_EXPORT int hipF_rbm_update_mse(khStream_t s, int32_t N, int32_t H, int32_t V, const float *pos_vis, int32_t ldpv,
+                                  const float *pos_hid, int32_t ldph, const float *neg_vis, int32_t ldnv,
+                                  const float *neg_hid, int32_t ldnh, float lr, float momentum, float l2, float *W,
+                                  int32_t ldw, float *dW, int32_t lddw, float *vis_bias, float *dvis_bias,
+                                  float *hid_bias, float *dhid_bias, double *mse_loss) {
+  KH_REQUIRE(vis_bias && dvis_bias && hid_bias && dhid_bias && mse_loss);
+  static const bool own_launch = getenv("KALDI_HIP_RBM_BIAS_LAUNCH") != nullptr;  // for A/B measurements
+  RbmBiasVectors bv = {vis_bias, dvis_bias, hid_bias, dhid_bias, false, mse_loss, false};
+  if (!own_launch) {
+    int rc = rbm_update_weights(s, N, H, V, pos_vis, ldpv, pos_hid, ldph, neg_vis, ldnv, neg_hid, ldnh, lr, momentum, l2, W,
+                                ldw, dW, lddw, &bv);
+    if (rc != KH_OK || (bv.done && bv.mse_done)) return rc;
+  }
+  // the error in a launch of its own (before the weights where none of them has run yet; after is as good: it reads
+  // the reconstruction and the data only)
+  MatrixDim d = {N, V, ldnv};
+  KH_REQUIRE(ldnv == ldpv);
+  int rc = hipF_mse_eval(s, neg_vis, pos_vis, nullptr, nullptr, mse_loss, d);
+  if (rc != KH_OK || bv.done) return rc;
+  if (own_launch) {
+    rc = hipF_rbm_update_weights(s, N, H, V, pos_vis, ldpv, pos_hid, ldph, neg_vis, ldnv, neg_hid, ldnh, lr, momentum, l2, W,
+                                 ldw, dW, lddw);
+    if (rc != KH_OK) return rc;
+  }
   return hipF_rbm_update_bias(s, N, H, V, pos_vis, ldpv, pos_hid, ldph, neg_vis, ldnv, neg_hid, ldnh, lr, momentum, vis_bias,
                               dvis_bias, hid_bias, dhid_bias);
 }

@@ -70,6 +70,12 @@ struct GemmParams {
   // term) and ceil(N / 64) for the visible ones (columns of B / B2; bias2_io, bcorr2)
   float *bias2_io;
   float *bcorr2;
+  // ... and, mse_rows > 0, the reconstruction error of the step by one more workgroup per row behind those:
+  // mse_loss[0] += 1/2 * sum((B - B2)^2) over the mse_rows x N elements (B = the reconstruction, B2 = the data)
+  int mse_rows;
+  float *mse_row_sq;     // mse_rows floats of scratch
+  unsigned *mse_ticket;  // arrival counter, zero at rest
+  double *mse_loss;
 #ifdef KH_GEMM_STAMPS
   unsigned long long *stamps;
 #endif
@@ -1141,8 +1147,17 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
   } else if constexpr (EPI == EPI_RBM) {
     static_assert(gemm_lds_floats<BM, BN, BK, WK, A_KMAJOR, B_KMAJOR>() >= 2048, "bias statistics need 2048 floats");
     const int ntiles = p.tiles_m * p.tiles_n * p.splitk;
-    if ((int)blockIdx.x >= ntiles) rbm_bias_tile(p, lds, (int)blockIdx.x - ntiles);
-    else gemm_tile<BM, BN, BK, WK, A_KMAJOR, B_KMAJOR, EPI, VEC>(p, lds, blockIdx.x, ntiles);
+    const int extra = (int)blockIdx.x - ntiles;
+    if (extra < 0) {
+      gemm_tile<BM, BN, BK, WK, A_KMAJOR, B_KMAJOR, EPI, VEC>(p, lds, blockIdx.x, ntiles);
+    } else if (extra < p.bias_tiles) {
+      rbm_bias_tile(p, lds, extra);
+    } else {
+      const int r = extra - p.bias_tiles;  // one row of the reconstruction error
+      kh::mse_row_and_total(p.B + (size_t)r * p.ldb, p.B2 + (size_t)r * p.ldb, nullptr, p.N, p.mse_row_sq, r, p.mse_rows,
+                            p.mse_ticket, p.mse_loss, lds, reinterpret_cast<double *>(lds + 32),
+                            reinterpret_cast<unsigned *>(lds + 16));
+    }
   } else {
     gemm_tile<BM, BN, BK, WK, A_KMAJOR, B_KMAJOR, EPI, VEC>(p, lds, blockIdx.x, gridDim.x);
   }
@@ -1207,7 +1222,8 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(GemmParams p, const fl
 
 template <int BM, int BN, int WK, bool AK, bool BK_, int EPI>
 void launch_cfg(hipStream_t st, const GemmParams &p, bool vec) {
-  const int nblk = p.tiles_m * p.tiles_n * p.splitk + ((EPI == EPI_UPDATE && BM != 64) || EPI == EPI_RBM ? p.bias_tiles : 0);
+  const int nblk = p.tiles_m * p.tiles_n * p.splitk + ((EPI == EPI_UPDATE && BM != 64) || EPI == EPI_RBM ? p.bias_tiles : 0) +
+                   (EPI == EPI_RBM ? p.mse_rows : 0);
   if (vec)
     hipLaunchKernelGGL((gemm_kernel<BM, BN, kBK, WK, AK, BK_, EPI, true>), dim3(nblk), dim3(256), p.dyn_lds, st, p);
   else

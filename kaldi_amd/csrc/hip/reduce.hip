@@ -564,10 +564,8 @@ __global__ __launch_bounds__(kSoftmaxThreads) void softmax_xent_vec_kernel(float
 }
 
 // ---- fused Mse / MseProgress Eval ------------------------------------------------------------
-// One workgroup per row: diff = a - b (stored when asked for) and the row's sum of squares; the workgroup that
-// arrives last (the stream's arrival counter, as in xent_finish) adds the rows up in double, in a fixed order, and
-// adds half of that to the loss -- one launch (a second one-workgroup kernel for the sum cost ~2.5-4 us per call on
-// the critical path of an RBM step).  Row sums travel write-through / past the L1 like the Xent row results.
+// One workgroup per row, one launch: kh::mse_row_and_total (a second one-workgroup kernel for the total cost
+// ~2.5-4 us per call on the critical path of an RBM step).
 __global__ __launch_bounds__(256) void mse_rows_kernel(const float *a, const float *b, float *diff, float *row_sq,
                                                        MatrixDim d, unsigned *ticket, double *loss) {
   __shared__ float red[16];
@@ -575,33 +573,8 @@ __global__ __launch_bounds__(256) void mse_rows_kernel(const float *a, const flo
   __shared__ unsigned arrived;
   const int r = blockIdx.x;
   const size_t base = (size_t)r * d.stride;
-  float acc = 0.f;
-  for (int c = threadIdx.x; c < d.cols; c += 256) {
-    const float df = a[base + c] - b[base + c];
-    if (diff) diff[base + c] = df;
-    acc += df * df;
-  }
-  const float t = kh::block_sum(acc, red);
-  if (threadIdx.x == 0) {
-    __hip_atomic_store(row_sq + r, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the row's sum has reached the L2
-    arrived = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  __syncthreads();
-  if (arrived != gridDim.x - 1) return;
-  double tot = 0.0;
-  for (int i = threadIdx.x; i < d.rows; i += 256)
-    tot += (double)__hip_atomic_load(row_sq + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  sd[threadIdx.x] = tot;
-  __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) {
-    if (threadIdx.x < o) sd[threadIdx.x] += sd[threadIdx.x + o];
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) {
-    loss[0] += 0.5 * sd[0];
-    __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
+  kh::mse_row_and_total(a + base, b + base, diff ? diff + base : nullptr, d.cols, row_sq, r, d.rows, ticket, loss, red,
+                        sd, &arrived);
 }
 
 }  // namespace

@@ -148,7 +148,11 @@ void MseProgress::Eval(const CuMatrix<BaseFloat> &net_out, const CuMatrix<BaseFl
   diff->Resize(net_out.NumRows(), net_out.NumCols());
   KALDI_ASSERT(net_out.Stride() == target.Stride() && diff->Stride() == net_out.Stride());
   CU_SAFE_CALL(hipF_mse_eval(S(), net_out.Data(), target.Data(), diff->Data(), NULL, stats_.Loss(), net_out.Dim()));
-  frames_progress_ += net_out.NumRows();
+  Evaluated(net_out.NumRows());
+}
+
+void MseProgress::Evaluated(int32 rows) {
+  frames_progress_ += rows;
   if (frames_progress_ > progress_step_) {
     double loss = 0.0;
     stats_.Fetch(NULL, NULL, &loss);

@@ -99,6 +99,11 @@ class MseProgress {
   ~MseProgress() {}
   /// like Mse::Eval, and logs the running MSE every progress_step frames
   void Eval(const CuMatrix<BaseFloat> &net_out, const CuMatrix<BaseFloat> &target, CuMatrix<BaseFloat> *diff);
+  /// Eval in two parts, for a caller whose own launch adds 1/2 * sum((net_out - target)^2) of `rows` frames to the
+  /// device counter (Rbm::RbmUpdate with a loss): the counter to add to, and the bookkeeping of Eval (frame
+  /// counts, progress log) once that launch is queued on the stream.
+  double *DeviceLoss() { return stats_.Loss(); }
+  void Evaluated(int32 rows);
   std::string Report();
 
  private:

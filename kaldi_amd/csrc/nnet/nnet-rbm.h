@@ -16,6 +16,9 @@ class RbmBase : public UpdatableComponent {
   virtual void Reconstruct(const CuMatrix<BaseFloat> &hid_state, CuMatrix<BaseFloat> *vis_probs) = 0;
   virtual void RbmUpdate(const CuMatrix<BaseFloat> &pos_vis, const CuMatrix<BaseFloat> &pos_hid,
                          const CuMatrix<BaseFloat> &neg_vis, const CuMatrix<BaseFloat> &neg_hid) = 0;
+  /// the same step, which also adds the reconstruction error 1/2 * sum((neg_vis - pos_vis)^2) to a device counter
+  virtual void RbmUpdate(const CuMatrix<BaseFloat> &pos_vis, const CuMatrix<BaseFloat> &pos_hid,
+                         const CuMatrix<BaseFloat> &neg_vis, const CuMatrix<BaseFloat> &neg_hid, double *mse_loss) = 0;
   virtual RbmNodeType VisType() const = 0;
   virtual RbmNodeType HidType() const = 0;
   virtual void WriteAsNnet(std::ostream &os, bool binary) const = 0;
@@ -92,8 +95,8 @@ class Rbm : public RbmBase {
     vis_hid_corr_.Resize(vis_hid_.NumRows(), vis_hid_.NumCols());  // no-op after the first call
     vis_bias_corr_.Resize(vis_bias_.Dim());
     hid_bias_corr_.Resize(hid_bias_.Dim());
-    // One stream: both weight statistics in one launch where the operands allow it, then both bias statistics in
-    // one small launch.  (The bias half and the reconstruction error used to run on a second stream beside the
+    // One stream: both weight statistics in one launch where the operands allow it, the bias statistics inside it
+    // (else in one small launch).  (The bias half and the reconstruction error used to run on a second stream beside the
     // GEMMs: the event packets that fork and join the streams left ~6 us gaps in the main stream's queue, three
     // per step, more than the small kernels take on their own.)
     CU_SAFE_CALL(hipF_rbm_update(S(), pos_vis.NumRows(), output_dim_, input_dim_, pos_vis.Data(), pos_vis.Stride(),
@@ -101,6 +104,26 @@ class Rbm : public RbmBase {
                                  neg_hid.Stride(), learn_rate_, momentum_, l2_penalty_, vis_hid_.Data(),
                                  vis_hid_.Stride(), vis_hid_corr_.Data(), vis_hid_corr_.Stride(), vis_bias_.Data(),
                                  vis_bias_corr_.Data(), hid_bias_.Data(), hid_bias_corr_.Data()));
+  }
+
+  /// RbmUpdate and the reconstruction error of the same step, 1/2 * sum((neg_vis - pos_vis)^2) added to the device
+  /// counter `mse_loss` (MseProgress::DeviceLoss): what the CD-1 loop's mse.Eval(neg_vis, pos_vis, ...) adds, without
+  /// a launch of its own where the weight launch can carry it (hipF_rbm_update_mse).
+  void RbmUpdate(const CuMatrix<BaseFloat> &pos_vis, const CuMatrix<BaseFloat> &pos_hid,
+                 const CuMatrix<BaseFloat> &neg_vis, const CuMatrix<BaseFloat> &neg_hid, double *mse_loss) {
+    CuProfileScope p("Rbm::RbmUpdate");
+    KALDI_ASSERT(pos_vis.NumRows() == pos_hid.NumRows() && pos_vis.NumRows() == neg_vis.NumRows() &&
+                 pos_vis.NumRows() == neg_hid.NumRows() && pos_vis.NumCols() == neg_vis.NumCols() &&
+                 pos_hid.NumCols() == neg_hid.NumCols() && pos_vis.NumCols() == input_dim_ &&
+                 pos_hid.NumCols() == output_dim_ && pos_vis.Stride() == neg_vis.Stride());
+    vis_hid_corr_.Resize(vis_hid_.NumRows(), vis_hid_.NumCols());  // no-op after the first call
+    vis_bias_corr_.Resize(vis_bias_.Dim());
+    hid_bias_corr_.Resize(hid_bias_.Dim());
+    CU_SAFE_CALL(hipF_rbm_update_mse(S(), pos_vis.NumRows(), output_dim_, input_dim_, pos_vis.Data(), pos_vis.Stride(),
+                                     pos_hid.Data(), pos_hid.Stride(), neg_vis.Data(), neg_vis.Stride(), neg_hid.Data(),
+                                     neg_hid.Stride(), learn_rate_, momentum_, l2_penalty_, vis_hid_.Data(),
+                                     vis_hid_.Stride(), vis_hid_corr_.Data(), vis_hid_corr_.Stride(), vis_bias_.Data(),
+                                     vis_bias_corr_.Data(), hid_bias_.Data(), hid_bias_corr_.Data(), mse_loss));
   }
 
   RbmNodeType VisType() const { return vis_type_; }

@@ -71,7 +71,7 @@ int main(int argc, char *argv[]) {
     MseProgress mse;
 
     FeatureUploader uploader(cachesize);
-    CuMatrix<BaseFloat> feats_transf, pos_vis, pos_hid, neg_vis, neg_hid, dummy_mse_mat;
+    CuMatrix<BaseFloat> feats_transf, pos_vis, pos_hid, neg_vis, neg_hid;
     std::vector<int32> dummy_cache_vec;
     CuStlVector<int32> dummy_targets;
 
@@ -108,9 +108,11 @@ int main(int argc, char *argv[]) {
         }
         // negative phase
         rbm.Reconstruct(neg_hid, &neg_vis);
-        mse.Eval(neg_vis, pos_vis, &dummy_mse_mat);
         rbm.Propagate(neg_vis, &neg_hid);
-        rbm.RbmUpdate(pos_vis, pos_hid, neg_vis, neg_hid);
+        // the update and the reconstruction error mse.Eval(neg_vis, pos_vis, ...) of the reference's loop in one
+        // call: the error only reads the two visible matrices and rides in the update's weight launch
+        rbm.RbmUpdate(pos_vis, pos_hid, neg_vis, neg_hid, mse.DeviceLoss());
+        mse.Evaluated(neg_vis.NumRows());
         tot_t += pos_vis.NumRows();
       }
       if (feature_reader.Done()) break;

@@ -630,6 +630,8 @@ def test_rbm_cd1(hip, V, H, vt, ht):
                dnh.ptr, dnh.stride)
         np.testing.assert_allclose(dnh.numpy(), ref["neg_hid"], rtol=2e-5, atol=2e-5)
         # (copies for the two-call form below: weights and bias statistics as launches of their own)
+        W_before, dW_before = dW.numpy(), ddW.numpy()
+        vb_before, dvb_before, hb_before, dhb_before = dvb.numpy(), ddvb.numpy(), dhb.numpy(), ddhb.numpy()
         cW, cdW = dev(h, dW.numpy()), dev(h, ddW.numpy())
         cvb, cdvb = dev(h, dvb.numpy()[0], False), dev(h, ddvb.numpy()[0], False)
         chb, cdhb = dev(h, dhb.numpy()[0], False), dev(h, ddhb.numpy()[0], False)
@@ -643,6 +645,23 @@ def test_rbm_cd1(hip, V, H, vt, ht):
                dnh.ptr, dnh.stride, f32(0.01), f32(0.5), cvb.ptr, cdvb.ptr, chb.ptr, cdhb.ptr)
         for a, b in ((dW, cW), (ddW, cdW), (dvb, cvb), (ddvb, cdvb), (dhb, chb), (ddhb, cdhb)):
             assert np.array_equal(a.numpy(), b.numpy())
+        # hipF_rbm_update_mse: the same step plus the reconstruction error, which rides in the weight launch too:
+        # every result as above, the error as hipF_mse_eval adds it up (same bits) and as the oracle does
+        eW, edW = dev(h, W_before), dev(h, dW_before)
+        evb, edvb = dev(h, vb_before[0], False), dev(h, dvb_before[0], False)
+        ehb, edhb = dev(h, hb_before[0], False), dev(h, dhb_before[0], False)
+        loss_a, loss_b = h.DevMatrix(1, 1, np.float64, pitched=False), h.DevMatrix(1, 1, np.float64, pitched=False)
+        for _ in range(2):   # (twice: the arrival counter must be back at zero for the second call)
+            h.call("hipF_mse_eval", None, dnv.ptr, dpv.ptr, None, None, loss_a.ptr, dnv.dim)
+        h.call("hipF_mse_eval", None, dnv.ptr, dpv.ptr, None, None, loss_b.ptr, dnv.dim)
+        h.call("hipF_rbm_update_mse", None, N, H, V, dpv.ptr, dpv.stride, dph.ptr, dph.stride, dnv.ptr, dnv.stride,
+               dnh.ptr, dnh.stride, f32(0.01), f32(0.5), f32(2e-4), eW.ptr, eW.stride, edW.ptr, edW.stride, evb.ptr,
+               edvb.ptr, ehb.ptr, edhb.ptr, loss_b.ptr)
+        for a, b in ((dW, eW), (ddW, edW), (dvb, evb), (ddvb, edvb), (dhb, ehb), (ddhb, edhb)):
+            assert np.array_equal(a.numpy(), b.numpy())
+        assert loss_b.numpy()[0, 0] == loss_a.numpy()[0, 0] and loss_a.numpy()[0, 0] > 0
+        want = 0.5 * float(((dnv.numpy().astype(np.float64) - pos_vis) ** 2).sum())
+        assert abs(loss_a.numpy()[0, 0] - 2 * want) <= 1e-5 * 2 * want
         np.testing.assert_allclose(dW.numpy(), rbm.W, rtol=1e-4, atol=1e-6)
         np.testing.assert_allclose(ddW.numpy(), rbm.W_corr, rtol=1e-3, atol=1e-7)
         np.testing.assert_allclose(dvb.numpy()[0], rbm.vis_bias, rtol=1e-4, atol=1e-6)
