@@ -243,17 +243,25 @@ def test_xent(hip, shape):
     assert abs(loss.numpy()[0, 0] - 2 * x.loss) <= 1e-5 * abs(2 * x.loss)
 
 
-def test_mse_eval(hip):
+@pytest.mark.parametrize("rows,cols", [(256, 440), (1, 7), (3, 2048), (1000, 33)])
+def test_mse_eval(hip, rows, cols):
+    """Mse::Eval (nnet-loss.cc:123-158) in one launch: row sums, then the workgroup that arrives last adds them up.
+    One row, more rows than that workgroup has threads, ragged widths; the loss accumulates over calls (the arrival
+    counter is back at zero after each) and the optional outputs may be left out."""
     h = hip
-    a, b = rnd((256, 440), 15), rnd((256, 440), 16)
+    a, b = rnd((rows, cols), 15), rnd((rows, cols), 16)
     rdiff, rrow, rloss = O.mse_eval(a, b)
     da, db, dd = dev(h, a), dev(h, b), dev(h, np.zeros_like(a))
-    row = h.DevMatrix(1, 256, f32, pitched=False)
+    row = h.DevMatrix(1, rows, f32, pitched=False)
     loss = h.DevMatrix(1, 1, np.float64, pitched=False)
     h.call("hipF_mse_eval", None, da.ptr, db.ptr, dd.ptr, row.ptr, loss.ptr, da.dim)
     close(dd.numpy(), rdiff)
     close(row.numpy()[0], rrow, 1e-5)
     assert abs(loss.numpy()[0, 0] - rloss) < 1e-5 * rloss
+    first = loss.numpy()[0, 0]
+    for _ in range(2):
+        h.call("hipF_mse_eval", None, da.ptr, db.ptr, None, None, loss.ptr, da.dim)
+    assert abs(loss.numpy()[0, 0] - 3 * first) <= 1e-12 * 3 * first
 
 
 def test_gathers(hip):
