@@ -511,6 +511,11 @@ __global__ __launch_bounds__(kSoftmaxThreads) void softmax_xent_vec_kernel(float
   const bool t_ok = (t >= 0 && t < cols);
   const __amdgpu_buffer_rsrc_t rsy = row_rsrc(y + (size_t)r * ldy, xf.write_post ? cols : 0);  // 0 columns: nothing is written
   const __amdgpu_buffer_rsrc_t rsd = row_rsrc(xf.diff + (size_t)r * xf.lddiff, cols);
+  // Order of the rest: arg-max and target posterior first (registers only), the row's results and this
+  // workgroup's arrival next, the row stores after that -- so the write acknowledgement and the counter's round
+  // trip (two trips to the memory side) pass while the 2 x 36 KB of the row are being stored, not after them --
+  // and last the check whether this workgroup arrived last.  (Stores first, the barrier behind the arg-max waited
+  // for every store of every thread, and the two round trips came on top.)
   MaxId m;
   m.v = -1e21f;
   m.i = -1;
@@ -521,19 +526,15 @@ __global__ __launch_bounds__(kSoftmaxThreads) void softmax_xent_vec_kernel(float
     // from memory by the two-kernel form (a fused multiply-add here would differ in the last bit)
 #pragma clang fp contract(off)
     const int c = (threadIdx.x + k * kSoftmaxThreads) * 4;
-    float e[4] = {v[k].x * inv, v[k].y * inv, v[k].z * inv, v[k].w * inv};
-    row_store4(rsy, c, e[0], e[1], e[2], e[3]);
+    const float e[4] = {v[k].x * inv, v[k].y * inv, v[k].z * inv, v[k].w * inv};
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const bool in = c + j < cols;
       const bool up = in && e[j] > m.v;  // ascending columns, strict: the first maximum stays
       m.v = up ? e[j] : m.v;
       m.i = up ? c + j : m.i;
-      const bool hit = in && (c + j == t);
-      pt = hit ? e[j] : pt;
-      e[j] = hit ? e[j] - 1.0f : e[j];
+      pt = (in && (c + j == t)) ? e[j] : pt;
     }
-    row_store4(rsd, c, e[0], e[1], e[2], e[3]);
   }
   m = wave_best(m);  // per-thread columns ascend, lower index wins ties: the first maximum of the row
 #pragma unroll
@@ -545,6 +546,8 @@ __global__ __launch_bounds__(kSoftmaxThreads) void softmax_xent_vec_kernel(float
     spt[wid] = pt;
   }
   __syncthreads();
+  __shared__ unsigned arrived;
+  unsigned arrival = 0;
   if (threadIdx.x == 0) {
     MaxId b;
     b.v = sv[0];
@@ -559,8 +562,25 @@ __global__ __launch_bounds__(kSoftmaxThreads) void softmax_xent_vec_kernel(float
     }
     const float ptv = t_ok ? ptot : 0.0f;
     row_result_store(xf.log_post, xf.max_id, r, logf(ptv < 1e-20f ? 1e-20f : ptv), b.i);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this row's results have reached the L2
+    arrival = __hip_atomic_fetch_add(xf.tail.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
-  xent_finish(xf.tail, xf.tgt, xf.log_post, xf.max_id, xf.rows);
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+#pragma clang fp contract(off)
+    const int c = (threadIdx.x + k * kSoftmaxThreads) * 4;
+    float e[4] = {v[k].x * inv, v[k].y * inv, v[k].z * inv, v[k].w * inv};
+    row_store4(rsy, c, e[0], e[1], e[2], e[3]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) e[j] = (c + j < cols && c + j == t) ? e[j] - 1.0f : e[j];
+    row_store4(rsd, c, e[0], e[1], e[2], e[3]);
+  }
+  asm volatile("" ::: "memory");
+  if (threadIdx.x == 0) arrived = arrival;
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // (LDS only: the row stores stay in flight)
+  if (arrived != gridDim.x - 1) return;
+  xent_accum_block(xf.tgt, xf.log_post, xf.max_id, xf.tail.counters, xf.tail.loss, xf.rows);
+  if (threadIdx.x == 0) __hip_atomic_store(xf.tail.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // ---- fused Mse / MseProgress Eval ------------------------------------------------------------
