@@ -606,10 +606,13 @@ def test_affine_forward_xent_equals_two_calls(hip, N, O_, I):
     assert int(cnt_a.numpy()[0, 1]) == N and abs(loss_a.numpy()[0, 0] - xo.loss) <= 1e-5 * abs(xo.loss)
 
 
-@pytest.mark.parametrize("V,H,vt,ht", [(440, 2048, "gauss", "bern"), (2048, 2048, "bern", "bern"), (24, 32, "bern", "gauss")])
-def test_rbm_cd1(hip, V, H, vt, ht):
+@pytest.mark.parametrize("V,H,vt,ht,N", [(440, 2048, "gauss", "bern", 256), (2048, 2048, "bern", "bern", 256),
+                                         (24, 32, "bern", "gauss", 256), (24, 32, "bern", "bern", 48), (22, 30, "gauss", "bern", 64)])
+def test_rbm_cd1(hip, V, H, vt, ht, N):
+    """Two CD-1 steps against the oracle (nnet-rbm.h:136-223).  Bunches of 256 take the one-launch update (both
+    weight statistics, the bias statistics and the reconstruction error in it); 48 rows (not whole K tiles) and
+    widths that are no multiples of 4 take the separate launches: same results either way."""
     h = hip
-    N = 256
     rs = np.random.RandomState(50)
     W = rnd((H, V), 51, 0.1)
     vb, hb = rnd((V,), 52, 0.1), rnd((H,), 53, 0.1)
