@@ -186,6 +186,38 @@ def test_two_steps_swbd_shape_match_oracle(hip, nn, tmp_path):
     _steps_against_oracle(hip, nn, tmp_path, layers, dims, [(x, tgt), (x2, tgt2)], 0.008, 0.0)
 
 
+def test_batched_forward_swbd_shape_row_invariant(hip, nn, tmp_path):
+    """Nnet::Feedforward (nnet-nnet.cc:120-145) on the Switchboard-sized network over a batch of 4100 rows with the
+    row-invariant GEMM plans nnet-forward uses when it batches utterances (hipK_gemm_row_invariant): posteriors
+    against the numpy oracle on a sample of rows (1e-4 relative), against the free plans on every row, and the
+    property that gives the plans their name -- a row's output has the same bits whatever shares its batch."""
+    h = hip
+    dims, N = [1320] + [2048] * 7 + [9000], 4100
+    layers, x, _ = _sigmoid_dnn(41, dims, N)
+    (tmp_path / "m.nnet").write_bytes(O.write_nnet(layers, True))
+    tr = nn.Trainer(str(tmp_path / "m.nnet"))
+    dx = h.DevMatrix.from_numpy(x)
+    out = h.DevMatrix(N, dims[-1])
+    try:
+        h.call("hipK_gemm_row_invariant", 1)
+        tr.feedforward(dx, out)
+        full = out.numpy()
+        # rows 1000..2999 as a batch of their own, and rows 4000..4099 (a ragged tail of 100)
+        for r0, r1 in ((1000, 3000), (4000, 4100)):
+            sub_in = h.DevMatrix.from_numpy(x[r0:r1])
+            sub_out = h.DevMatrix(r1 - r0, dims[-1])
+            tr.feedforward(sub_in, sub_out)
+            assert np.array_equal(sub_out.numpy(), full[r0:r1])
+    finally:
+        h.call("hipK_gemm_row_invariant", 0)
+    tr.feedforward(dx, out)
+    np.testing.assert_allclose(out.numpy(), full, rtol=1e-4, atol=1e-9)
+    rows = np.random.RandomState(42).choice(N, 48, replace=False)
+    want = O.Nnet(layers).feedforward(x[rows])
+    np.testing.assert_allclose(full[rows], want, rtol=1e-4, atol=1e-9)
+    assert np.allclose(full.sum(axis=1), 1.0, atol=1e-4)
+
+
 def test_forward_tool_matches_reference(hip, nn, tmp_path):
     g = load("forward_small.npz")
     (tmp_path / "m.nnet").write_bytes(g["model"].tobytes())
