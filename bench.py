@@ -309,6 +309,13 @@ def main():
         elapsed = float(t_el.item())
 
     frames, correct, loss = trainer.stats() if kind == "train" else (0, 0, 0.0)
+    # sanity figure of the run: mean cross-entropy of training (ln(classes) for random labels at the start), the
+    # posteriors' row sums of the last forward batch
+    check = {"frames": frames, "mean_xent": round(loss / max(frames, 1), 4)}
+    if kind == "forward":
+        last = post.numpy()[:batch_rows[(args.steps - 1) % len(utts)]]
+        check = {"rows": int(last.shape[0]), "posterior_row_sum_min": round(float(last.sum(axis=1).min()), 5),
+                 "posterior_row_sum_max": round(float(last.sum(axis=1).max()), 5)}
     done = sum(frames_of(i) for i in range(args.steps))  # frames of this rank inside the timed region
     value = world * done / elapsed
 
@@ -380,7 +387,7 @@ def main():
                                          "frac": round(v[2] / v[1] * 1e3 / F32_MFMA_PEAK_TFLOPS if v[1] else 0.0, 4)}
                                         for k, v in sorted(classes.items())]},
             "order": "40 set-up steps (first touch; the clock climbs out of its idle state), %d steps with GEMM launches bracketed by events (roofline), %d warm-up steps, %d timed steps" % (roof_steps, args.warmup, args.steps),
-            "check": {"frames": frames, "mean_xent": round(loss / max(frames, 1), 4)},
+            "check": check,
         }
         if world == 1 and not args.no_cpu_baseline and kind == "train":
             out["cpu_baseline"] = cpu_baseline(dims, model_path, tmp)
