@@ -211,7 +211,8 @@ constexpr int gemm_lds_floats() {
 // One output tile by one workgroup: tile `bid` of the `nblk` this product is cut into (`bid` must be
 // congruent to blockIdx.x modulo 8 for the XCD-aware decode below to keep its meaning).
 // NW = 8 (only with WK = 1): a 512-thread workgroup, waves arranged 2 x 4 over the tile.
-template <int BM, int BN, int BK, int WK, bool A_KMAJOR, bool B_KMAJOR, int EPI, bool VEC, int NW = 4>
+// KTAIL: the variant for K ranges that end inside a tile (see mask_tail below).
+template <int BM, int BN, int BK, int WK, bool A_KMAJOR, bool B_KMAJOR, int EPI, bool VEC, int NW = 4, bool KTAIL = false>
 __device__ __forceinline__ void gemm_tile(const GemmParams &p, float *lds, const int bid, const int nblk) {
   constexpr int NT = 64 * NW;
   static_assert(NW == 4 || (NW == 8 && WK == 1), "4 waves, or 8 waves without a K split over waves");
@@ -318,6 +319,35 @@ __device__ __forceinline__ void gemm_tile(const GemmParams &p, float *lds, const
   const int nk1 = DUAL_EPI ? p.nk1 : 0;
   const __amdgpu_buffer_rsrc_t rsrc_a2 = __builtin_amdgcn_make_buffer_rsrc((void *)(DUAL_EPI ? p.A2 : p.A), 0, p.a_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrc_b2 = __builtin_amdgcn_make_buffer_rsrc((void *)(DUAL_EPI ? p.B2 : p.B), 0, p.b_bytes, 0x00020000);
+  // KTAIL: the K tail (a last tile that [kbeg, kend) fills only in part) as one more tile of the fast loop.  Before
+  // the tail tile's loads are issued, the offsets of the units whose k lies past the end are replaced by one beyond
+  // the operand's footprint, which a buffer load answers with 0, so the tile's remaining products add 0 -- the same
+  // sums as the guarded tail.  The replacement runs once, under a uniform branch.  Needs whole 16-byte units on
+  // either side of the end where K is the contiguous direction (K a multiple of 4; rows of k are whole units).
+  // A variant of its own, launched only for such K: in the common kernel the mere presence of this code cost the
+  // launches without a tail 0.4-0.5 us each (another register allocation), and selecting the offset beside every
+  // load 7 % of a whole training step.  The guarded element-wise tail -- loads, then an unpipelined tile -- takes
+  // 5.8 k cycles where a full tile takes 1.0 k (32 x 64 tile, K split over two waves).
+  static_assert(!KTAIL || (NT % (BKT / 4) == 0 && NT % (BM / 4) == 0 && NT % (BN / 4) == 0), "unit -> k mapping below");
+  bool tail_fast = false;
+  if constexpr (KTAIL)
+    tail_fast = VEC && p.a_bytes > 0 && ((kend - kbeg) % BKT) != 0 && (((A_KMAJOR || B_KMAJOR) ? ((kend - kbeg) & 3) : 0) == 0);
+  auto mask_tail = [&]() {
+    if constexpr (KTAIL) {
+      if (!tail_fast) return;
+      // k (inside a tile) of this thread's unit 0 of either operand; unit u lies a compile-time step further
+      const int ka0 = A_KMAJOR ? (tid % (BKT / 4)) * 4 : tid / (BM / 4);
+      const int kb0 = B_KMAJOR ? (tid % (BKT / 4)) * 4 : tid / (BN / 4);
+      constexpr int KA_STEP = A_KMAJOR ? 0 : NT / (BM / 4), KB_STEP = B_KMAJOR ? 0 : NT / (BN / 4);
+      const int rem = (kend - kbeg) % BKT;
+#pragma unroll
+      for (int u = 0; u < A_UNITS; ++u)
+        if (ka0 + u * KA_STEP >= rem) oa[u] = p.a_bytes;
+#pragma unroll
+      for (int u = 0; u < B_UNITS; ++u)
+        if (kb0 + u * KB_STEP >= rem) ob[u] = p.b_bytes;
+    }
+  };
   auto load_fast = [&](int kt) {
     if (DUAL_EPI && nk1 > 0 && kt >= nk1) {
 #pragma unroll
@@ -543,7 +573,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams &p, float *lds, const
   };
 
   // K-tiles completely inside the split take the fast loads; at most one tail tile does not.
-  const int nfull = (VEC && p.a_bytes > 0) ? (kend - kbeg) / BKT : 0;
+  const int nfull = (VEC && p.a_bytes > 0) ? ((KTAIL && tail_fast) ? nkt : (kend - kbeg) / BKT) : 0;
   constexpr int G = BK / 8;           // k-groups per tile
   // which K-loop: whole-tile operand fragments (more registers: 2 waves per SIMD at most) or
   // group-by-group fragments (the update GEMMs, which run 4 workgroups per CU)
@@ -580,12 +610,18 @@ __device__ __forceinline__ void gemm_tile(const GemmParams &p, float *lds, const
     //     the whole next tile (8 read instructions per gap, consecutive gaps).
     // Measured (tools/mfma_probe4.hip): 1068 cycles per 64x64x32 tile against 1024 of MFMA, where
     // reading group by group takes ~1250.
+    if constexpr (KTAIL) {
+      if (nfull == 1) mask_tail();
+    }
     load_fast(0);
     KH_STAMP(1);
     store_tiles(0);
     KH_STAMP(2);
     __syncthreads();
     KH_STAMP(3);
+    if constexpr (KTAIL) {
+      if (nfull == 2) mask_tail();
+    }
     if (nfull > 1) load_fast(1);
     Frag fr[2][G];
 #pragma unroll
@@ -642,6 +678,9 @@ __device__ __forceinline__ void gemm_tile(const GemmParams &p, float *lds, const
             prefetch_acc(a);
             npre = a + 1;
           }
+      }
+      if constexpr (KTAIL) {
+        if (kt == nfull - 3) mask_tail();  // this tile's body issues the first loads of the last tile
       }
       tile_body(std::false_type(), par_tag);
     };
@@ -1130,7 +1169,7 @@ __device__ __forceinline__ void update_tile(const GemmParams &p, float *lds, con
   gemm_tile<BM, BN, BK, WK, A_KMAJOR, B_KMAJOR, EPI, VEC, NW>(p, lds, bid, ntiles);
 }
 
-template <int BM, int BN, int BK, int WK, bool A_KMAJOR, bool B_KMAJOR, int EPI, bool VEC>
+template <int BM, int BN, int BK, int WK, bool A_KMAJOR, bool B_KMAJOR, int EPI, bool VEC, bool KTAIL = false>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
   __shared__ __attribute__((aligned(16))) float lds[gemm_lds_floats<BM, BN, BK, WK, A_KMAJOR, B_KMAJOR>()];
   if constexpr (EPI == EPI_UPDATE) {
@@ -1159,7 +1198,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
                             reinterpret_cast<unsigned *>(lds + 16));
     }
   } else {
-    gemm_tile<BM, BN, BK, WK, A_KMAJOR, B_KMAJOR, EPI, VEC>(p, lds, blockIdx.x, gridDim.x);
+    gemm_tile<BM, BN, BK, WK, A_KMAJOR, B_KMAJOR, EPI, VEC, 4, KTAIL>(p, lds, blockIdx.x, gridDim.x);
   }
 }
 
@@ -1224,6 +1263,15 @@ template <int BM, int BN, int WK, bool AK, bool BK_, int EPI>
 void launch_cfg(hipStream_t st, const GemmParams &p, bool vec) {
   const int nblk = p.tiles_m * p.tiles_n * p.splitk + ((EPI == EPI_UPDATE && BM != 64) || EPI == EPI_RBM ? p.bias_tiles : 0) +
                    (EPI == EPI_RBM ? p.mse_rows : 0);
+  // K ends inside a tile: the variant that runs the tail in the fast loop (forward and back-propagation products on
+  // the tiles whose waves split K -- the shapes of a 256-row bunch; K = 440, 1320, 9000 of the RM- and
+  // Switchboard-sized nets)
+  if constexpr ((EPI == EPI_BIAS_ACT || EPI == EPI_DSIG) && WK > 1 && KH_SCHED >= 2) {
+    if (vec && p.splitk == 1 && p.a_bytes > 0 && p.K % (kBK * WK) != 0 && (((AK || BK_) ? (p.K & 3) : 0) == 0)) {
+      hipLaunchKernelGGL((gemm_kernel<BM, BN, kBK, WK, AK, BK_, EPI, true, true>), dim3(nblk), dim3(256), p.dyn_lds, st, p);
+      return;
+    }
+  }
   if (vec)
     hipLaunchKernelGGL((gemm_kernel<BM, BN, kBK, WK, AK, BK_, EPI, true>), dim3(nblk), dim3(256), p.dyn_lds, st, p);
   else
