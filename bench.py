@@ -246,8 +246,10 @@ def main():
                 trainer.set_data_parallel(world)
             elif os.environ.get("KALDI_BENCH_LOOPBACK_DP"):
                 # rehearsal of the data-parallel step on one GPU: gradient GEMM, (local) all-reduce, shared step
+                # (KALDI_BENCH_LOOPBACK_ONE_RANK: the stand-in does the device work of ONE of the n ranks -- its shard
+                # of the sums and of the step -- instead of playing all of them; timing only)
                 n = int(os.environ["KALDI_BENCH_LOOPBACK_DP"])
-                h.call("hipK_comm_init_loopback", n)
+                h.call("hipK_comm_init_loopback_one_rank" if os.environ.get("KALDI_BENCH_LOOPBACK_ONE_RANK") else "hipK_comm_init_loopback", n)
                 trainer.set_data_parallel(n)
         # a synthetic, already shuffled frame cache resident in HBM (each rank its own frames)
         cache_rows = 16 * BUNCH

@@ -326,6 +326,23 @@ typedef struct {
 } khAffineUpdate;
 int hipF_affine_update_group(khStream_t s, int32_t count, const khAffineUpdate *items);
 
+/* The first half of the data-parallel update (no counterpart in the reference, which trains on one GPU) for
+ * several layers in ONE launch of the same grouped kernel: item i writes the raw sums of its layer,
+ *   gW = e^T * in   (O x I, leading dimension ldg; the floats between I and ldg of a row are left alone)
+ *   gb = colsum(e)  (O floats),
+ * which the caller exchanges between the ranks and then applies (hipF_sgd_apply_segments, hipF_affine_apply).
+ * K = the bunch is summed in one piece in a fixed order: the same bits whichever items share the launch.
+ * Items that do not qualify for the grouped kernel (operands or gW not 16-byte aligned, I or ldg not a multiple
+ * of 4, more than 2 GiB) are computed on their own by hipF_gemm and hipF_add_row_sum_mat. */
+typedef struct {
+  int32_t N, O, I;
+  const float *e; int32_t lde;
+  const float *in; int32_t ldin;
+  float *gW; int32_t ldg;
+  float *gb;
+} khAffineGradient;
+int hipF_affine_gradient_group(khStream_t s, int32_t count, const khAffineGradient *items);
+
 /* The two halves of hipF_affine_update on their own, so that a caller can queue them on different
  * streams (the bias half reads only e; the weight half reads only e and in besides W):
  *   weights: corr = gscale * e^T * in + momentum * corr ; W_out = (1 - l2) * W_in - lr * corr
@@ -353,6 +370,20 @@ int hipF_affine_apply(khStream_t s, int32_t O, int32_t I, const float *grad, int
 /* The same step on `count` consecutive floats of a weight matrix's memory, taken as one long row (row padding
  * included: gradient 0 there): for a rank that steps only its shard of a layer.  corr may be NULL only when
  * momentum == 0.  Element for element the arithmetic of hipF_affine_apply. */
+/* The same step on elements [first, first + count) of a parameter arena that holds several layers one after
+ * another (weights and biases, row padding included: gradient 0 there), from the gradient at the same positions
+ * of `grad`: element i is stepped with the hyper-parameters of the segment [begin, end) that contains it and left
+ * alone when no segment does.  For a rank that steps its shard of a run of layers after a reduce-scatter.  first,
+ * count and every segment bound must be multiples of 4, the three bases 16-byte aligned, at most
+ * KH_MAX_SGD_SEGMENTS segments, sorted and disjoint.  corr may be NULL only when every momentum is 0.  Element
+ * for element the arithmetic of hipF_affine_apply (a bias is a segment with l2 = 0). */
+#define KH_MAX_SGD_SEGMENTS 32
+typedef struct {
+  size_t begin, end;
+  float gscale, momentum, lr, l2;
+} khSgdSegment;
+int hipF_sgd_apply_segments(khStream_t s, int32_t nseg, const khSgdSegment *segs, size_t first, size_t count,
+                            const float *grad, float *w, float *corr);
 int hipF_sgd_apply_flat(khStream_t s, size_t count, const float *grad, float gscale, float momentum, float lr,
                         float l2, float *w, float *corr);
 
@@ -438,6 +469,10 @@ int hipK_comm_init(const unsigned char id[KH_COMM_ID_BYTES], int rank, int nrank
  * code path (gradient -> all-reduce -> step) be validated on one GPU: training on a bunch X with
  * a loopback of n equals single-process training on n stacked copies of X. */
 int hipK_comm_init_loopback(int nranks);
+/* The stand-in as ONE rank of nranks (rank 0) for timing runs: reduce-scatter sums, and hipK_comm_shard_range
+ * names, only that rank's shard, the all-gather brings nothing in -- the device work of one real rank without the
+ * link traffic.  The other shards of the weights are then never stepped: the numbers of such a run mean nothing. */
+int hipK_comm_init_loopback_one_rank(int nranks);
 int hipK_comm_destroy(void);
 int hipK_comm_rank(int *rank, int *nranks);
 /* in-place sum all-reduce of count floats on stream s (ordered with the kernels on s) */

@@ -8,6 +8,7 @@
 #include "nnet/nnet-loss.h"
 #include "nnet/nnet-nnet.h"
 #include "nnet/nnet-rbm.h"
+#include "util/table-types.h"
 
 using namespace kaldi;
 
@@ -267,6 +268,43 @@ int nnet1_substitute_job(const char *spec, int rank, char *out, int out_len) {
   if (static_cast<int>(r.size()) + 1 > out_len) return -1;
   memcpy(out, r.c_str(), r.size() + 1);
   return 0;
+}
+
+int nnet1_table_scan_shard(const char *rspecifier, int num_ranks, int rank, long long *kept, long long *kept_frames,
+                           long long *payload_bytes) {
+  CAPI_TRY
+  if (!rspecifier || num_ranks < 1 || rank < 0 || rank >= num_ranks) return -1;
+  kaldi::ShardAssigner shard(num_ranks);
+  kaldi::SequentialBaseFloatMatrixReader reader(
+      rspecifier, [&shard, rank](const std::string &, int32 rows) { return shard.Assign(rows) == rank; });
+  long long n = 0, frames = 0;
+  for (; !reader.Done(); reader.Next()) {
+    ++n;
+    frames += reader.Value().NumRows();
+  }
+  if (kept) *kept = n;
+  if (kept_frames) *kept_frames = frames;
+  if (payload_bytes) *payload_bytes = static_cast<long long>(reader.PayloadBytesRead());
+  return 0;
+  CAPI_CATCH(-1)
+}
+
+int nnet1_comm_nonce(long parent_pid, char *out, int out_len) {
+  if (!out || out_len <= 0) return -1;
+  const std::string r = kaldi::CommNonce(parent_pid);
+  if (static_cast<int>(r.size()) + 1 > out_len) return -1;
+  memcpy(out, r.c_str(), r.size() + 1);
+  return 0;
+}
+
+int nnet1_comm_id_file_write(const char *file, const char *nonce, const unsigned char *id, int id_bytes) {
+  if (!file || !nonce || !id || id_bytes <= 0) return -1;
+  return kaldi::WriteCommIdFile(file, nonce, id, id_bytes) ? 0 : -1;
+}
+
+int nnet1_comm_id_file_read(const char *file, const char *nonce, unsigned char *id, int id_bytes) {
+  if (!file || !nonce || !id || id_bytes <= 0) return -1;
+  return kaldi::ReadCommIdFile(file, nonce, id, id_bytes) ? 1 : 0;
 }
 
 }  // extern "C"

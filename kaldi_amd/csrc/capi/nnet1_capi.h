@@ -50,6 +50,16 @@ int nnet1_rand_stream(unsigned int seed, int n, int *out);
  * substitution in output specifiers. */
 int nnet1_shard_assign(int num_ranks, int n, const long long *num_frames, int *rank_out);
 int nnet1_substitute_job(const char *spec, int rank, char *out, int out_len);
+/* Walks a table of float matrices as rank `rank` of the sharded nnet-forward does (other ranks' entries are
+ * skipped on their headers): entries and frames kept, payload bytes brought in.  -1 on any read error, a
+ * table cut off inside a skipped entry included. */
+int nnet1_table_scan_shard(const char *rspecifier, int num_ranks, int rank, long long *kept, long long *kept_frames,
+                           long long *payload_bytes);
+/* The launch nonce of the RCCL id file as a rank whose parent process is parent_pid computes it from the
+ * environment, and the id file's writer / reader (read: 1 = this launch's complete file, 0 = not yet). */
+int nnet1_comm_nonce(long parent_pid, char *out, int out_len);
+int nnet1_comm_id_file_write(const char *file, const char *nonce, const unsigned char *id, int id_bytes);
+int nnet1_comm_id_file_read(const char *file, const char *nonce, unsigned char *id, int id_bytes);
 #ifdef __cplusplus
 }
 #endif

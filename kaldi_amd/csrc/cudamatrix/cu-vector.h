@@ -12,11 +12,12 @@ class CuVector {
   typedef CuVector<Real> ThisType;
 
  public:
-  CuVector() : dim_(0), data_(NULL) {}
-  explicit CuVector(size_t dim) : dim_(0), data_(NULL) { Resize(dim); }
-  CuVector(ThisType &&o) noexcept : dim_(o.dim_), data_(o.data_) {
+  CuVector() : dim_(0), data_(NULL), owner_(true) {}
+  explicit CuVector(size_t dim) : dim_(0), data_(NULL), owner_(true) { Resize(dim); }
+  CuVector(ThisType &&o) noexcept : dim_(o.dim_), data_(o.data_), owner_(o.owner_) {
     o.dim_ = 0;
     o.data_ = NULL;
+    o.owner_ = true;
   }
   ~CuVector() { Destroy(); }
 
@@ -37,13 +38,23 @@ class CuVector {
     return *this;
   }
   void Destroy() {
-    if (data_) {
+    if (data_ && owner_) {
       CuDevice::Instantiate().Synchronize();
       CU_SAFE_CALL(hipK_free(data_));
     }
     data_ = NULL;
     dim_ = 0;
+    owner_ = true;
   }
+  /// Makes this vector a window onto `dim` floats owned elsewhere (its own memory, if any, is freed); a later
+  /// Resize to another size lets go of the window and allocates.
+  void AttachView(Real *data, size_t dim) {
+    Destroy();
+    data_ = data;
+    dim_ = dim;
+    owner_ = false;
+  }
+  bool IsView() const { return !owner_; }
   ThisType &CopyFromVec(const CuVector<Real> &src) {
     Resize(src.Dim());
     CU_SAFE_CALL(hipK_memcpy(S(), data_, src.data_, dim_ * sizeof(Real), 2));
@@ -119,6 +130,7 @@ class CuVector {
   }
   size_t dim_;
   Real *data_;
+  bool owner_;  // false: a window onto memory owned elsewhere (AttachView)
   CuVector(const ThisType &) = delete;
   ThisType &operator=(const ThisType &) = delete;
 };

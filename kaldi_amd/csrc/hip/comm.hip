@@ -12,6 +12,7 @@ struct Comm {
   ncclComm_t comm = nullptr;
   int rank = 0, nranks = 1;
   bool loopback = false;  // stand-in for nranks replicas that all hold this process's data
+  bool one_rank = false;  // ... that does the device work of rank 0 only (timing runs)
 };
 template <typename T>
 __global__ void scale_kernel(T *buf, size_t n, T f) {
@@ -63,6 +64,7 @@ KH_EXPORT int hipK_comm_init(const unsigned char id[KH_COMM_ID_BYTES], int rank,
   c.rank = rank;
   c.nranks = nranks;
   c.loopback = false;
+  c.one_rank = false;
   return KH_OK;
 }
 
@@ -74,6 +76,14 @@ KH_EXPORT int hipK_comm_init_loopback(int nranks) {
   Comm &c = comm();
   c.nranks = nranks;
   c.loopback = nranks > 1;
+  c.one_rank = false;
+  return KH_OK;
+}
+
+KH_EXPORT int hipK_comm_init_loopback_one_rank(int nranks) {
+  int rc = hipK_comm_init_loopback(nranks);
+  if (rc != KH_OK) return rc;
+  comm().one_rank = comm().loopback;
   return KH_OK;
 }
 
@@ -86,6 +96,7 @@ KH_EXPORT int hipK_comm_destroy(void) {
   c.rank = 0;
   c.nranks = 1;
   c.loopback = false;
+  c.one_rank = false;
   return KH_OK;
 }
 
@@ -154,9 +165,9 @@ KH_EXPORT int hipK_comm_group_end(void) {
 KH_EXPORT int hipK_comm_shard_range(size_t shard_count, size_t *first, size_t *count) {
   KH_REQUIRE(first != nullptr && count != nullptr);
   Comm &c = comm();
-  // the loopback stand-in plays every rank in turn, so it owns every shard
+  // the loopback stand-in plays every rank in turn, so it owns every shard (as one rank: rank 0's)
   *first = c.loopback ? 0 : (size_t)c.rank * shard_count;
-  *count = c.loopback ? (size_t)c.nranks * shard_count : shard_count;
+  *count = (c.loopback && !c.one_rank) ? (size_t)c.nranks * shard_count : shard_count;
   return KH_OK;
 }
 
@@ -168,7 +179,7 @@ KH_EXPORT int hipF_reduce_scatter_sum(khStream_t s, float *buf, size_t shard_cou
   if (c.nranks == 1 && !(force_rccl() && c.comm)) return KH_OK;
   if (c.loopback) {
     // every replica holds the same values: each shard's sum is nranks times it
-    const size_t count = shard_count * c.nranks;
+    const size_t count = c.one_rank ? shard_count : shard_count * c.nranks;
     hipLaunchKernelGGL(scale_kernel<float>, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, kh::pick(s), buf, count,
                        (float)c.nranks);
     return kh::launch_status();

@@ -427,6 +427,41 @@ __global__ __launch_bounds__(256) void affine_apply_kernel(int O, int I, const f
   }
 }
 
+// the same step on a range of a parameter arena that holds several layers: the hyper-parameters of an element are
+// those of the segment that contains it (kernel arguments; a wave's elements lie in at most two segments)
+struct SgdSegments {
+  int n;
+  unsigned begin[KH_MAX_SGD_SEGMENTS], end[KH_MAX_SGD_SEGMENTS];  // in units of 4 floats
+  float g[KH_MAX_SGD_SEGMENTS], mom[KH_MAX_SGD_SEGMENTS], lr[KH_MAX_SGD_SEGMENTS], l2[KH_MAX_SGD_SEGMENTS];
+};
+__global__ __launch_bounds__(256) void sgd_apply_segments_kernel(SgdSegments sg, unsigned first4, unsigned count4,
+                                                                 const float *grad, float *w, float *corr) {
+  const unsigned stride = gridDim.x * 256;
+  for (unsigned q = blockIdx.x * 256 + threadIdx.x; q < count4; q += stride) {
+    const unsigned u = first4 + q;
+    int k = -1;
+    for (int i = 0; i < sg.n; ++i)
+      if (u >= sg.begin[i] && u < sg.end[i]) k = i;
+    if (k < 0) continue;
+    const float g = sg.g[k], mom = sg.mom[k], lr = sg.lr[k], l2 = sg.l2[k];
+    float gv[4], cv[4], wv[4];
+    *reinterpret_cast<float4 *>(gv) = reinterpret_cast<const float4 *>(grad)[u];
+    *reinterpret_cast<float4 *>(wv) = reinterpret_cast<const float4 *>(w)[u];
+    if (mom != 0.f) *reinterpret_cast<float4 *>(cv) = reinterpret_cast<const float4 *>(corr)[u];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {  // (the arithmetic of affine_apply_kernel)
+      float cc = g * gv[i];
+      if (mom != 0.f) cc = kh::mul_add(mom, cv[i], cc);
+      cv[i] = cc;
+      float x = wv[i];
+      if (l2 != 0.f) x = -l2 * x + x;
+      wv[i] = -lr * cc + x;
+    }
+    reinterpret_cast<float4 *>(w)[u] = *reinterpret_cast<float4 *>(wv);
+    if (corr) reinterpret_cast<float4 *>(corr)[u] = *reinterpret_cast<float4 *>(cv);
+  }
+}
+
 __global__ void bias_apply_kernel(int O, const float *bgrad, float g, float mom, float lr, float *bias, float *bcorr) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= O) return;
@@ -481,6 +516,34 @@ KH_EXPORT int hipF_sgd_apply_flat(khStream_t s, size_t count, const float *grad,
   else
     hipLaunchKernelGGL((affine_apply_kernel<1>), dim3(gx, 1), dim3(256), 0, st, 1, n, grad, n, gscale, momentum, lr, l2, w, n,
                        corr, n);
+  return kh::launch_status();
+}
+
+KH_EXPORT int hipF_sgd_apply_segments(khStream_t s, int32_t nseg, const khSgdSegment *segs, size_t first, size_t count,
+                                      const float *grad, float *w, float *corr) {
+  KH_CHECK_INIT();
+  KH_REQUIRE(nseg >= 0 && nseg <= KH_MAX_SGD_SEGMENTS && (nseg == 0 || segs != nullptr));
+  if (count == 0 || nseg == 0) return KH_OK;
+  KH_REQUIRE(grad && w && kh::aligned16(grad) && kh::aligned16(w) && (!corr || kh::aligned16(corr)));
+  KH_REQUIRE(first % 4 == 0 && count % 4 == 0 && (first + count) / 4 < ((size_t)1 << 32));
+  SgdSegments sg;
+  sg.n = nseg;
+  for (int i = 0; i < nseg; ++i) {
+    KH_REQUIRE(segs[i].begin % 4 == 0 && segs[i].end % 4 == 0 && segs[i].begin <= segs[i].end && segs[i].end / 4 < ((size_t)1 << 32));
+    KH_REQUIRE(i == 0 || segs[i].begin >= segs[i - 1].end);
+    KH_REQUIRE(segs[i].momentum == 0.f || corr != nullptr);
+    sg.begin[i] = (unsigned)(segs[i].begin / 4);
+    sg.end[i] = (unsigned)(segs[i].end / 4);
+    sg.g[i] = segs[i].gscale;
+    sg.mom[i] = segs[i].momentum;
+    sg.lr[i] = segs[i].lr;
+    sg.l2[i] = segs[i].l2;
+  }
+  const unsigned count4 = (unsigned)(count / 4);
+  unsigned gx = (count4 + 255) / 256;
+  if (gx > 4096) gx = 4096;  // a few float4 per thread at most for the large shards: enough loads in flight per CU
+  hipLaunchKernelGGL(sgd_apply_segments_kernel, dim3(gx), dim3(256), 0, kh::pick(s), sg, (unsigned)(first / 4), count4, grad, w,
+                     corr);
   return kh::launch_status();
 }
 
@@ -761,6 +824,72 @@ KH_EXPORT int hipF_affine_update_group(khStream_t s, int32_t count, const khAffi
       int rc = flush();
       if (rc != KH_OK) return rc;
       rc = run_gemm<EPI_UPDATE>(s, false, false, p, /*allow_split=*/false);
+      if (rc != KH_OK) return rc;
+      continue;
+    }
+    g.p[g.n] = p;
+    const int blocks = p.tiles_m * p.tiles_n;
+    g.first[g.n + 1] = g.first[g.n] + ((blocks + 7) & ~7);
+    flops += 2.0 * p.M * p.N * p.K;
+    if (++g.n == kMaxGroup) {
+      const int rc = flush();
+      if (rc != KH_OK) return rc;
+    }
+  }
+  return flush();
+}
+
+KH_EXPORT int hipF_affine_gradient_group(khStream_t s, int32_t count, const khAffineGradient *items) {
+  KH_CHECK_INIT();
+  KH_REQUIRE(count >= 0 && (count == 0 || items != nullptr));
+  hipStream_t st = kh::pick(s);
+  for (int i = 0; i < count; ++i) {
+    const khAffineGradient &u = items[i];
+    KH_REQUIRE(u.N > 0 && u.O > 0 && u.I > 0);
+    KH_REQUIRE(u.e && u.in && u.gW && u.gb && u.lde >= u.O && u.ldin >= u.I && u.ldg >= u.I);
+  }
+  // tiles as in hipF_affine_update_group: 128 x 128 where the call fills two rounds of their slots
+  static const int big_rounds = getenv("KALDI_HIP_GRAD_GROUP_BIG_TILES") ? atoi(getenv("KALDI_HIP_GRAD_GROUP_BIG_TILES")) : 4;
+  bool big = group_big;
+  if (big) {
+    const int cus = kh::ctx().num_cu > 0 ? kh::ctx().num_cu : 256;
+    long long big_tiles = 0;
+    for (int i = 0; i < count; ++i) big_tiles += (long long)((items[i].O + 127) / 128) * ((items[i].I + 127) / 128);
+    if (big_tiles < (long long)big_rounds * cus) big = false;
+  }
+  GemmGroup g;
+  memset(&g, 0, sizeof(g));
+  double flops = 0.0;
+  auto flush = [&]() -> int {
+    if (g.n == 0) return KH_OK;
+    {
+      TimedLaunch tl(st, flops);
+      launch_grad_group(st, g, big);
+    }
+    g.n = 0;
+    g.first[0] = 0;
+    flops = 0.0;
+    return kh::launch_status();
+  };
+  for (int i = 0; i < count; ++i) {
+    const khAffineGradient &u = items[i];
+    GemmParams p = base_params(u.O, u.I, u.N, u.e, u.lde, u.in, u.ldin, u.gW, u.ldg);
+    const double cbytes = ((double)(u.O - 1) * u.ldg + u.I) * 4.0;
+    const bool cvec = u.I % 4 == 0 && u.ldg % 4 == 0 && kh::aligned16(u.gW) && cbytes < 2147483648.0;
+    p.c_bytes = cvec ? (int)cbytes : 0;
+    p.bias_io = u.gb;
+    p.bias_tiles = (u.O + 63) / 64;
+    const bool vec = kh::aligned16(p.A) && kh::aligned16(p.B) && (p.lda % 4 == 0) && (p.ldb % 4 == 0);
+    Plan plan = {big ? 3 : 0, 1, ((p.K + kBK - 1) / kBK) * kBK};
+    apply_plan(p, plan, false, false);
+    p.n_fastest = p.tiles_m > 2 * p.tiles_n ? 1 : 0;
+    if (!vec || !cvec || p.a_bytes == 0 || force_bm > 0) {
+      int rc = flush();
+      if (rc != KH_OK) return rc;
+      rc = hipF_gemm(s, KH_TRANS, KH_NO_TRANS, u.O, u.I, u.N, 1.0f, u.e, u.lde, u.in, u.ldin, 0.0f, u.gW, u.ldg);
+      if (rc != KH_OK) return rc;
+      ::MatrixDim d = {u.N, u.O, u.lde};
+      rc = hipF_add_row_sum_mat(s, 1.0f, u.e, d, 0.0f, u.gb);
       if (rc != KH_OK) return rc;
       continue;
     }

@@ -25,7 +25,8 @@ enum Epi {
   EPI_BIAS_ACT = 2,// C = act(bias[col] + acc)
   EPI_DSIG = 3,    // C = acc * y * (1 - y)
   EPI_UPDATE = 4,  // corr = g*acc + mom*corr ; W = W - l2*W - lr*corr
-  EPI_RBM = 5      // dW = g*acc + dW - lrl2*W ; W += dW
+  EPI_RBM = 5,     // dW = g*acc + dW - lrl2*W ; W += dW
+  EPI_GRAD = 6     // C = alpha*acc, the update product without the weight step (data-parallel gradient), 16-byte stores
 };
 
 struct GemmParams {
@@ -94,6 +95,7 @@ struct GemmGroup {
   GemmParams p[kMaxGroup];
 };
 void launch_update_group(hipStream_t st, const GemmGroup &g, bool big);  // big: 128 x 128 tiles, else 64 x 64
+void launch_grad_group(hipStream_t st, const GemmGroup &g, bool big);    // the same launch with the EPI_GRAD epilogue
 
 // launches the main kernel for tile configuration `cfg` (index into the planner's table) and operand layout
 template <int EPI>
@@ -177,6 +179,8 @@ __device__ __forceinline__ void epi_store(const GemmParams &p, int row, int col,
     d = -p.l2 * wv + d;
     *dw = d;
     p.Wout[(size_t)row * p.ldwout + col] = d + wv;
+  } else if (EPI == EPI_GRAD) {
+    p.C[(size_t)row * p.ldc + col] = p.alpha * val;
   }
 }
 
@@ -237,7 +241,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams &p, float *lds, const
   // The products of the dependent chain (forward, back-propagation) outrank the weight updates that
   // fill the compute units beside them: where waves of both share a SIMD, the chain's issue first.
 #ifndef KH_NO_CHAIN_PRIO
-  if (EPI != EPI_UPDATE && EPI != EPI_RBM) __builtin_amdgcn_s_setprio(3);
+  if (EPI != EPI_UPDATE && EPI != EPI_RBM && EPI != EPI_GRAD) __builtin_amdgcn_s_setprio(3);
 #endif
   // Which way the run walks decides which operand an XCD reads whole: down the rows first it covers every row
   // tile of a few column tiles (all of A, a slice of B); along the columns first the other way round -- the host
@@ -577,7 +581,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams &p, float *lds, const
   constexpr int G = BK / 8;           // k-groups per tile
   // which K-loop: whole-tile operand fragments (more registers: 2 waves per SIMD at most) or
   // group-by-group fragments (the update GEMMs, which run 4 workgroups per CU)
-  constexpr bool kWholeTile = (KH_SCHED == 2) || (KH_SCHED == 3 && EPI != EPI_UPDATE && EPI != EPI_RBM);
+  constexpr bool kWholeTile = (KH_SCHED == 2) || (KH_SCHED == 3 && EPI != EPI_UPDATE && EPI != EPI_RBM && EPI != EPI_GRAD);
   constexpr int MG = 4 * TM * TN;     // MFMAs per group
   static_assert(G >= 4 && G % 2 == 0, "BK must be a multiple of 16, at least 32");
   int kt = 0;
@@ -922,6 +926,30 @@ __device__ __forceinline__ void gemm_tile(const GemmParams &p, float *lds, const
           }
         }
       }
+    } else if (EPI == EPI_GRAD && p.c_bytes != 0) {
+      // The update epilogue's way out without its weight step: every 32 x 32 accumulator block turned through the
+      // wave's own region of LDS so that a lane holds four consecutive columns of a row, stored 16 bytes per lane,
+      // write-through (the next reader is the exchange between the ranks, not this compute unit).
+      static_assert(NW * 32 * 36 <= 2 * (A_ELEMS + B_ELEMS), "transposition areas larger than the tile buffers");
+      typedef int v4i_t __attribute__((ext_vector_type(4)));
+      const __amdgpu_buffer_rsrc_t rsrc_c = __builtin_amdgcn_make_buffer_rsrc((void *)p.C, 0, p.c_bytes, 0x00020000);
+      float *xp = lds + wid * (32 * 36);
+      lds_barrier();  // every wave has read its last operand fragments
+#pragma unroll
+      for (int a = 0; a < TM * TN; ++a) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) xp[((r & 3) + 8 * (r >> 2) + 4 * lh) * 36 + li] = acc[a / TN][a % TN][r];
+        const int col = n0 + wn0 + (a % TN) * 32 + (lane & 7) * 4;
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+          const float4 v = *reinterpret_cast<const float4 *>(xp + ((lane >> 3) + 8 * pass) * 36 + (lane & 7) * 4);
+          if (col < p.N) {  // (rows past the matrix are dropped by the buffer bounds)
+            const v4i_t cv = {__float_as_int(p.alpha * v.x), __float_as_int(p.alpha * v.y), __float_as_int(p.alpha * v.z),
+                              __float_as_int(p.alpha * v.w)};
+            __builtin_amdgcn_raw_buffer_store_b128(cv, rsrc_c, vec_off(a, pass, p.ldc), 0, KH_UPDATE_STORE_AUX);
+          }
+        }
+      }
     } else
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -1008,6 +1036,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams &p, float *lds, const
 // launch (no launch of its own): bcorr = alpha * colsum(e) + mom * bcorr ; bias -= lr * bcorr.
 // The sums are taken exactly like bias_update_kernel's (16 interleaved row groups, combined in order 0..15),
 // so both give the same bits.
+template <bool GRAD = false>
 __device__ __forceinline__ void bias_update_tile(const GemmParams &p, float *lds, int tile) {
   KH_RT(10);
   const int tid = threadIdx.x;
@@ -1068,10 +1097,14 @@ __device__ __forceinline__ void bias_update_tile(const GemmParams &p, float *lds
     float t = 0.f;
 #pragma unroll
     for (int i = 0; i < 16; ++i) t += lds[i * 64 + tid];
-    float bc = p.alpha * t;
-    if (p.mom != 0.f) bc = kh::mul_add(p.mom, p.bcorr[c], bc);
-    if (p.bcorr) p.bcorr[c] = bc;
-    p.bias_io[c] = -p.lr * bc + p.bias_io[c];
+    if (GRAD) {
+      p.bias_io[c] = p.alpha * t;  // the bias gradient itself: the step follows the exchange between the ranks
+    } else {
+      float bc = p.alpha * t;
+      if (p.mom != 0.f) bc = kh::mul_add(p.mom, p.bcorr[c], bc);
+      if (p.bcorr) p.bcorr[c] = bc;
+      p.bias_io[c] = -p.lr * bc + p.bias_io[c];
+    }
   }
   KH_RT(13);
 }
@@ -1161,7 +1194,7 @@ __device__ __forceinline__ void update_tile(const GemmParams &p, float *lds, con
 #pragma unroll
       for (int h = 0; h < BM / 64; ++h)
         if (mi * (BM / 64) + h < p.bias_tiles) {
-          bias_update_tile(p, lds, mi * (BM / 64) + h);
+          bias_update_tile<EPI == EPI_GRAD>(p, lds, mi * (BM / 64) + h);
           __syncthreads();
         }
     }
@@ -1234,6 +1267,31 @@ void launch_update_group(hipStream_t st, const GemmGroup &g, bool big) {
   else hipLaunchKernelGGL(gemm_update_group_kernel<false>, dim3(g.first[g.n]), dim3(256), 0, st, g);
 }
 #endif  // KHG_DEFINE_UPDATE_GROUP
+
+#ifdef KHG_DEFINE_GRAD_GROUP
+// The same grouped launch for the data-parallel form of the step: every problem writes its raw product
+// e^T * in (and the column sums of e behind it, GemmParams::bias_io) instead of stepping the weights.
+template <bool BIG>
+__global__ __launch_bounds__(BIG ? 512 : 256) __attribute__((amdgpu_waves_per_eu(4, 4))) void gemm_grad_group_kernel(GemmGroup g) {
+  constexpr int BT = BIG ? 128 : 64;
+  __shared__ __attribute__((aligned(16))) float lds[gemm_lds_floats<BT, BT, kBK, 1, false, false>()];
+  const int b = blockIdx.x;
+  int idx = 0;
+#pragma unroll
+  for (int i = 1; i < kMaxGroup; ++i)
+    if (i < g.n && b >= g.first[i]) idx = i;
+  const GemmParams &p = g.p[idx];
+  const int bid = b - g.first[idx];
+  const int ntiles = p.tiles_m * p.tiles_n * p.splitk;
+  if (bid >= ntiles) return;
+  update_tile<BT, BT, kBK, 1, false, false, EPI_GRAD, true, BIG ? 8 : 4>(p, lds, bid, ntiles);
+}
+
+void launch_grad_group(hipStream_t st, const GemmGroup &g, bool big) {
+  if (big) hipLaunchKernelGGL(gemm_grad_group_kernel<true>, dim3(g.first[g.n]), dim3(512), 0, st, g);
+  else hipLaunchKernelGGL(gemm_grad_group_kernel<false>, dim3(g.first[g.n]), dim3(256), 0, st, g);
+}
+#endif  // KHG_DEFINE_GRAD_GROUP
 
 // ---- sum of split-K slabs + the element-wise step that follows the GEMM ------------------------
 template <int EPI, int VEC>

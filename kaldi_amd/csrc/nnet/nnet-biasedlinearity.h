@@ -184,11 +184,9 @@ class BiasedLinearity : public UpdatableComponent {
   /// gb = colsum(err)  into one contiguous buffer [gW (dim_out x dim_in, dense) | gb].
   void ComputeGradient(const CuMatrix<BaseFloat> &input, const CuMatrix<BaseFloat> &err, BaseFloat *grad_buf) {
     CuProfileScope p("BiasedLinearity::ComputeGradient");
-    const int32 n = input.NumRows();
-    CU_SAFE_CALL(hipF_gemm(S(), KH_TRANS, KH_NO_TRANS, output_dim_, input_dim_, n, 1.0f, err.Data(), err.Stride(),
-                           input.Data(), input.Stride(), 0.0f, grad_buf, input_dim_));
-    CU_SAFE_CALL(hipF_add_row_sum_mat(S(), 1.0f, err.Data(), err.Dim(), 0.0f,
-                                      grad_buf + static_cast<size_t>(output_dim_) * input_dim_));
+    khAffineGradient item = {input.NumRows(), output_dim_, input_dim_, err.Data(), err.Stride(), input.Data(), input.Stride(),
+                             grad_buf, input_dim_, grad_buf + static_cast<size_t>(output_dim_) * input_dim_};
+    CU_SAFE_CALL(hipF_affine_gradient_group(S(), 1, &item));
   }
   size_t GradientSize() const { return static_cast<size_t>(output_dim_) * input_dim_ + output_dim_; }
   /// second half: momentum, weight decay and the step from the (all-reduced) sums over
@@ -206,60 +204,111 @@ class BiasedLinearity : public UpdatableComponent {
     if (l2_upper_bound_ > 0.0) linearity_.ApplyRowL2UpperBound(l2_upper_bound_);
   }
 
-  /// Sharded data-parallel form.  The layer's weights are exchanged as the memory of the weight matrix itself
-  /// (dim_out rows of Stride() floats, padding included), cut into one shard per rank: possible when that
-  /// length divides evenly into 16-byte aligned shards and the step is element-wise (no L1 pass).
+  /// Sharded data-parallel form.  The parameters of the network's layers live one after another in arenas owned
+  /// by the Nnet (weights, gradients and, with momentum, corrections: the same layout in each): a layer takes
+  /// ParameterSpan() floats, the memory of its weight matrix as it is (dim_out rows of Stride() floats, padding
+  /// included) followed by its bias padded to a multiple of 64 floats.  The exchange between the ranks and the
+  /// element-wise step then work on runs of layers at a time.  Not with an L1 penalty, whose shrink needs the
+  /// reference's pass order.
   size_t WeightSpan() const { return static_cast<size_t>(output_dim_) * linearity_.Stride(); }
-  bool CanShard(int32 nranks) const {
-    const size_t n = WeightSpan();
-    return l1_penalty_ == 0.0 && nranks >= 1 && n % nranks == 0 && (n / nranks) % 4 == 0 &&
-           linearity_corr_.Stride() == linearity_.Stride();
+  size_t BiasSpan() const { return (static_cast<size_t>(output_dim_) + 63) & ~static_cast<size_t>(63); }
+  size_t ParameterSpan() const { return WeightSpan() + BiasSpan(); }
+  bool CanUseArena() const { return l1_penalty_ == 0.0 && linearity_corr_.Stride() == linearity_.Stride(); }
+  /// Moves weights and bias into `mem` (ParameterSpan() floats, 256-byte aligned, zero-filled by the caller) and
+  /// makes the component's matrix and vector windows onto it.
+  void MoveParametersTo(BaseFloat *mem) {
+    khStream_t s = S();
+    CU_SAFE_CALL(hipK_memcpy(s, mem, linearity_.Data(), WeightSpan() * sizeof(BaseFloat), 2));
+    CU_SAFE_CALL(hipK_memcpy(s, mem + WeightSpan(), bias_.Data(), output_dim_ * sizeof(BaseFloat), 2));
+    const MatrixIndexT stride = linearity_.Stride();
+    linearity_.AttachView(mem, output_dim_, input_dim_, stride);
+    bias_.AttachView(mem + WeightSpan(), output_dim_);
   }
-  size_t ShardedGradientSize() const { return WeightSpan() + output_dim_; }
-  /// gW = err^T * input laid out like the weight matrix (the padding of grad_buf's rows must be zero and is
-  /// left alone), gb = colsum(err) behind it
-  void ComputeGradientPitched(const CuMatrix<BaseFloat> &input, const CuMatrix<BaseFloat> &err, BaseFloat *grad_buf) {
-    CuProfileScope p("BiasedLinearity::ComputeGradient");
+  /// The same for the momentum state.
+  void MoveCorrectionsTo(BaseFloat *mem) {
+    khStream_t s = S();
+    CU_SAFE_CALL(hipK_memcpy(s, mem, linearity_corr_.Data(), WeightSpan() * sizeof(BaseFloat), 2));
+    CU_SAFE_CALL(hipK_memcpy(s, mem + WeightSpan(), bias_corr_.Data(), output_dim_ * sizeof(BaseFloat), 2));
+    const MatrixIndexT stride = linearity_corr_.Stride();
+    linearity_corr_.AttachView(mem, output_dim_, input_dim_, stride);
+    bias_corr_.AttachView(mem + WeightSpan(), output_dim_);
+  }
+  /// Gives the parameters back memory of their own (the arena is about to go away).
+  void OwnParametersAgain() {
+    if (linearity_.IsView()) {
+      CuMatrix<BaseFloat> w;
+      w.CopyFromMat(linearity_);
+      linearity_.Swap(&w);
+      CuVector<BaseFloat> b;
+      b.CopyFromVec(bias_);
+      bias_.AttachView(NULL, 0);
+      bias_.CopyFromVec(b);
+    }
+    if (linearity_corr_.IsView()) {
+      CuMatrix<BaseFloat> w;
+      w.CopyFromMat(linearity_corr_);
+      linearity_corr_.Swap(&w);
+      CuVector<BaseFloat> b;
+      b.CopyFromVec(bias_corr_);
+      bias_corr_.AttachView(NULL, 0);
+      bias_corr_.CopyFromVec(b);
+    }
+  }
+  /// This layer's item of the grouped gradient launch: gW = err^T * input laid out like the weight matrix and
+  /// gb = colsum(err) behind it, into `grad` (ParameterSpan() floats; the padding is never written).
+  void DescribeGradient(const CuMatrix<BaseFloat> &input, const CuMatrix<BaseFloat> &err, BaseFloat *grad,
+                        khAffineGradient *item) const {
     const int32 n = input.NumRows();
-    CU_SAFE_CALL(hipF_gemm(S(), KH_TRANS, KH_NO_TRANS, output_dim_, input_dim_, n, 1.0f, err.Data(), err.Stride(),
-                           input.Data(), input.Stride(), 0.0f, grad_buf, linearity_.Stride()));
-    CU_SAFE_CALL(hipF_add_row_sum_mat(S(), 1.0f, err.Data(), err.Dim(), 0.0f, grad_buf + WeightSpan()));
+    KALDI_ASSERT(err.NumRows() == n && err.NumCols() == output_dim_ && input.NumCols() == input_dim_);
+    item->N = n;
+    item->O = output_dim_;
+    item->I = input_dim_;
+    item->e = err.Data();
+    item->lde = err.Stride();
+    item->in = input.Data();
+    item->ldin = input.Stride();
+    item->gW = grad;
+    item->ldg = linearity_.Stride();
+    item->gb = grad + WeightSpan();
   }
-  /// The step on elements [first, first + count) of the weight memory from the summed gradient at the same
-  /// positions of grad_buf, and on the whole bias from the summed bias gradient behind it.
-  void ApplyGradientRange(const BaseFloat *grad_buf, size_t first, size_t count, int32 total_frames) {
-    CuProfileScope p("BiasedLinearity::ApplyGradient");
-    KALDI_ASSERT(l1_penalty_ == 0.0 && first + count <= WeightSpan());
-    const BaseFloat gscale = average_grad_ ? 1.0 / total_frames : 1.0;
-    const BaseFloat l2 = (l2_penalty_ != 0.0) ? learn_rate_ * l2_penalty_ * total_frames : 0.0;
-    CU_SAFE_CALL(hipF_sgd_apply_flat(S(), count, grad_buf + first, gscale, momentum_, learn_rate_, l2,
-                                     linearity_.Data() + first, KeepCorr() ? linearity_corr_.Data() + first : NULL));
-    CU_SAFE_CALL(hipF_sgd_apply_flat(S(), output_dim_, grad_buf + WeightSpan(), gscale, momentum_, learn_rate_, 0.0f,
-                                     bias_.Data(), KeepCorr() ? bias_corr_.Data() : NULL));
+  /// The two segments of the element-wise step (weights, bias) for this layer's place `offset` in the arenas,
+  /// for a step on the sums over total_frames frames.
+  void DescribeStep(size_t offset, int32 total_frames, khSgdSegment *w_seg, khSgdSegment *b_seg) const {
+    KALDI_ASSERT(l1_penalty_ == 0.0);
+    w_seg->begin = offset;
+    w_seg->end = offset + WeightSpan();
+    w_seg->gscale = average_grad_ ? 1.0 / total_frames : 1.0;
+    w_seg->momentum = momentum_;
+    w_seg->lr = learn_rate_;
+    w_seg->l2 = (l2_penalty_ != 0.0) ? learn_rate_ * l2_penalty_ * total_frames : 0.0;
+    *b_seg = *w_seg;
+    b_seg->begin = w_seg->end;
+    b_seg->end = offset + ParameterSpan();
+    b_seg->l2 = 0.0;
   }
-  /// after the shards of the new weights have been gathered
+  bool NeedsCorrections() const { return KeepCorr(); }
+  /// after the new weights have been gathered
   void FinishShardedStep() {
     if (l2_upper_bound_ > 0.0) linearity_.ApplyRowL2UpperBound(l2_upper_bound_);
   }
-  BaseFloat *WeightMemory() { return linearity_.Data(); }
 
   void SetLinearityWeight(const CuMatrix<BaseFloat> &weight, bool trans) {
     if (trans) {
       Matrix<BaseFloat> mat;
       weight.CopyToMat(&mat);
       mat.Transpose();
-      linearity_.CopyFromMat(mat);
+      AssignWeights(mat);
     } else {
-      linearity_.CopyFromMat(weight);
+      AssignWeights(weight);
     }
   }
   void SetLinearityWeight(const Matrix<BaseFloat> &weight, bool trans) {
     if (trans) {
       Matrix<BaseFloat> mat(weight);
       mat.Transpose();
-      linearity_.CopyFromMat(mat);
+      AssignWeights(mat);
     } else {
-      linearity_.CopyFromMat(weight);
+      AssignWeights(weight);
     }
   }
   const CuMatrix<BaseFloat> &GetLinearityWeight() { return linearity_; }
@@ -283,6 +332,24 @@ class BiasedLinearity : public UpdatableComponent {
  protected:
   static khStream_t S() { return CuDevice::Instantiate().Stream(); }
   bool KeepCorr() const { return momentum_ != 0.0 || keep_gradient_; }
+  /// (a weight matrix that is a window onto the network's parameter arena is written in place)
+  void AssignWeights(const CuMatrix<BaseFloat> &w) {
+    if (!linearity_.IsView()) {
+      linearity_.CopyFromMat(w);
+      return;
+    }
+    KALDI_ASSERT(w.NumRows() == linearity_.NumRows() && w.NumCols() == linearity_.NumCols());
+    linearity_.CopyFromMat(w, 0, w.NumRows(), 0, w.NumCols());
+  }
+  void AssignWeights(const Matrix<BaseFloat> &w) {
+    if (!linearity_.IsView()) {
+      linearity_.CopyFromMat(w);
+      return;
+    }
+    CuMatrix<BaseFloat> tmp;
+    tmp.CopyFromMat(w);
+    AssignWeights(tmp);
+  }
   void Forward(const CuMatrix<BaseFloat> &in, int act, CuMatrix<BaseFloat> *out) {
     CuProfileScope p("BiasedLinearity::Propagate");
     CU_SAFE_CALL(hipF_affine_forward(S(), act, KH_TRANS, in.NumRows(), output_dim_, input_dim_, in.Data(), in.Stride(),

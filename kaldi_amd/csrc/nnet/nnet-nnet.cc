@@ -14,7 +14,16 @@
 namespace kaldi {
 
 Nnet::~Nnet() {
-  for (size_t i = 0; i < nnet_.size(); ++i) delete nnet_[i];
+  for (size_t i = 0; i < nnet_.size(); ++i) delete nnet_[i];  // (windows onto the arenas free nothing)
+  if (dp_w_arena_ || dp_g_arena_ || dp_c_arena_) hipK_device_synchronize();
+  if (dp_w_arena_) hipK_free(dp_w_arena_);
+  if (dp_g_arena_) hipK_free(dp_g_arena_);
+  if (dp_c_arena_) hipK_free(dp_c_arena_);
+  for (size_t c = 0; c < dp_chunks_.size(); ++c) {
+    if (dp_chunks_[c].grad_ready) hipK_event_destroy(dp_chunks_[c].grad_ready);
+    if (dp_chunks_[c].weights_read) hipK_event_destroy(dp_chunks_[c].weights_read);
+    if (dp_chunks_[c].weights_ready) hipK_event_destroy(dp_chunks_[c].weights_ready);
+  }
   if (dp_grad_) hipK_free(dp_grad_);
   for (size_t i = 0; i < dp_layer_grad_.size(); ++i)
     if (dp_layer_grad_[i]) hipK_free(dp_layer_grad_[i]);
@@ -66,6 +75,7 @@ void Nnet::Propagate(const CuMatrix<BaseFloat> &in, CuMatrix<BaseFloat> *out) {
   else propagate_buf_[0].CopyFromMat(in);
   for (int32 i = 0; i < L; ++i) {
     const int act = fusion_ ? ActivationAfter(nnet_, i) : -1;
+    WaitForLayerWeights(i);
     if (act >= 0) {
       static_cast<BiasedLinearity *>(nnet_[i])->PropagateFused(propagate_buf_[i], act, &propagate_buf_[i + 2]);
       ++i;  // the activation has been applied
@@ -101,6 +111,7 @@ void Nnet::PropagateXent(const CuMatrix<BaseFloat> &in, const CuStlVector<int32>
   else propagate_buf_[0].CopyFromMat(in);
   for (int32 i = 0; i < L - 2; ++i) {
     const int act = ActivationAfter(nnet_, i);
+    WaitForLayerWeights(i);
     if (act >= 0) {
       static_cast<BiasedLinearity *>(nnet_[i])->PropagateFused(propagate_buf_[i], act, &propagate_buf_[i + 2]);
       ++i;
@@ -114,6 +125,7 @@ void Nnet::PropagateXent(const CuMatrix<BaseFloat> &in, const CuStlVector<int32>
   double *loss;
   xent->FusedBuffers(in.NumRows(), &log_post, &max_id, &counters, &loss);
   CuMatrix<BaseFloat> &last = propagate_buf_[L];
+  WaitForLayerWeights(L - 2);
   static_cast<BiasedLinearity *>(nnet_[L - 2])
       ->PropagateFusedXent(propagate_buf_[L - 2], target, keep_output, &last, diff, log_post, max_id, counters, loss);
   if (keep_output) {
@@ -181,11 +193,39 @@ void Nnet::Backpropagate(const CuMatrix<BaseFloat> &in_err, CuMatrix<BaseFloat> 
   const bool overlap = overlap_ && !dev.Profiling() && (dp_ranks_ > 1 || force_overlap);
   if (overlap && static_cast<int32>(layer_events_.size()) < L) layer_events_.resize(L, NULL);
   bool side_used = false, aux_used = false;
+  // Sharded exchange (see SetDataParallel): gradients of a chunk of layers in one launch on the main stream as
+  // soon as the error of the chunk's lowest layer exists, the chunk's reduce-scatter and the step on this rank's
+  // shard on the exchange stream beside the rest of the pass; the all-gathers of the new weights follow bottom-up
+  // behind the pass and are waited for layer by layer by the NEXT forward pass.
+  const bool arena = overlap && dp_ranks_ > 1 && dp_shard_ && SetupArenas();
+  if (arena) EnsureCorrectionArena();
+  const int32 total_frames = in_err.NumRows() * dp_ranks_;
+  dp_grad_items_.clear();
   // to be called before the back-propagation of layer i is queued
-  auto err_ready = [&](int32 i) {
+  auto err_ready = [&](int32 i, const CuMatrix<BaseFloat> &input, const CuMatrix<BaseFloat> &err_i) {
     if (!overlap || !nnet_[i]->IsUpdatable()) return;
     if (nnet_[i]->GetType() != Component::kBiasedLinearity) return;
     BiasedLinearity *bl = static_cast<BiasedLinearity *>(nnet_[i]);
+    if (arena) {
+      DpChunk &ch = dp_chunks_[dp_chunk_of_layer_[i]];
+      size_t k = 0;
+      while (ch.layers[k] != i) ++k;
+      khAffineGradient item;
+      bl->DescribeGradient(input, err_i, dp_g_arena_ + ch.offsets[k], &item);
+      dp_grad_items_.push_back(item);
+      // The errors of all the chunk's layers exist once that of its lowest layer does.  The top chunk's gradients
+      // are launched here, in front of that layer's back-propagation -- the largest message of the step starts
+      // as early as it can -- and are marked on their own; the other chunks' follow that back-propagation
+      // (update_or_defer below) and share its mark: every mark in the main stream's queue holds the next launch
+      // back by ~6 us (kernel trace).
+      if (i == ch.layers.back() && &ch == &dp_chunks_[0]) {
+        CuProfileScope p("BiasedLinearity::ComputeGradient");
+        CU_SAFE_CALL(hipF_affine_gradient_group(dev.MainStream(), static_cast<int32>(dp_grad_items_.size()), &dp_grad_items_[0]));
+        dp_grad_items_.clear();
+        CU_SAFE_CALL(hipK_event_record(ch.grad_ready, dev.MainStream()));
+      }
+      return;
+    }
     // (gather exchange with grouped updates: the one update launch runs behind the whole pass, in place)
     bl->SetDoubleBuffer((dp_ranks_ == 1 || dp_gather_) && !(dp_ranks_ > 1 && dp_gather_ && group_updates_));
     if (dp_ranks_ > 1) {
@@ -285,8 +325,7 @@ void Nnet::Backpropagate(const CuMatrix<BaseFloat> &in_err, CuMatrix<BaseFloat> 
         dp_layer_grad_size_.resize(L, 0);
         grad_events_.resize(L, NULL);
       }
-      const bool shard = dp_shard_ && bl->CanShard(dp_ranks_);
-      const size_t need = shard ? bl->ShardedGradientSize() : bl->GradientSize();
+      const size_t need = bl->GradientSize();
       if (need > dp_layer_grad_size_[i]) {
         if (dp_layer_grad_[i]) {
           CU_SAFE_CALL(hipK_device_synchronize());
@@ -296,35 +335,18 @@ void Nnet::Backpropagate(const CuMatrix<BaseFloat> &in_err, CuMatrix<BaseFloat> 
         CU_SAFE_CALL(hipK_malloc(&p, need * sizeof(BaseFloat)));
         dp_layer_grad_[i] = static_cast<BaseFloat *>(p);
         dp_layer_grad_size_[i] = need;
-        // (the sharded form relies on zeros in the padding of the gradient's rows)
-        CU_SAFE_CALL(hipK_memset_async(dev.SideStream(), p, 0, need * sizeof(BaseFloat)));
       }
       CU_SAFE_CALL(hipK_stream_wait_event(dev.SideStream(), layer_events_[i]));  // this layer's error exists
       {
         CuStreamScope scope(dev.SideStream());
-        if (shard) bl->ComputeGradientPitched(input, err, dp_layer_grad_[i]);
-        else bl->ComputeGradient(input, err, dp_layer_grad_[i]);
+        bl->ComputeGradient(input, err, dp_layer_grad_[i]);
       }
       dev.Order(dev.SideStream(), dev.AuxStream(), &grad_events_[i]);
       CU_SAFE_CALL(hipK_stream_wait_event(dev.AuxStream(), read_events_[i]));  // its back-propagation has read the weights
       {
         CuStreamScope scope(dev.AuxStream());
-        if (shard) {
-          // weight gradient: every rank receives the sum of its shard; bias gradient (small): summed everywhere
-          const size_t span = bl->WeightSpan(), per_rank = span / dp_ranks_;
-          CU_SAFE_CALL(hipK_comm_group_begin());
-          CU_SAFE_CALL(hipF_reduce_scatter_sum(dev.AuxStream(), dp_layer_grad_[i], per_rank));
-          CU_SAFE_CALL(hipF_allreduce_sum(dev.AuxStream(), dp_layer_grad_[i] + span, bl->OutputDim()));
-          CU_SAFE_CALL(hipK_comm_group_end());
-          size_t first = 0, count = 0;
-          CU_SAFE_CALL(hipK_comm_shard_range(per_rank, &first, &count));
-          bl->ApplyGradientRange(dp_layer_grad_[i], first, count, input.NumRows() * dp_ranks_);
-          CU_SAFE_CALL(hipF_allgather_shards(dev.AuxStream(), bl->WeightMemory(), per_rank));
-          bl->FinishShardedStep();
-        } else {
-          CU_SAFE_CALL(hipF_allreduce_sum(dev.AuxStream(), dp_layer_grad_[i], need));
-          bl->ApplyGradient(dp_layer_grad_[i], input.NumRows() * dp_ranks_);
-        }
+        CU_SAFE_CALL(hipF_allreduce_sum(dev.AuxStream(), dp_layer_grad_[i], need));
+        bl->ApplyGradient(dp_layer_grad_[i], input.NumRows() * dp_ranks_);
       }
       aux_used = true;
       return;
@@ -360,6 +382,47 @@ void Nnet::Backpropagate(const CuMatrix<BaseFloat> &in_err, CuMatrix<BaseFloat> 
   };
   std::vector<PendingUpdate> pending;
   auto update_or_defer = [&](int32 i, const CuMatrix<BaseFloat> &input, const CuMatrix<BaseFloat> &err) {
+    if (arena && nnet_[i]->IsUpdatable()) {
+      // (SetupArenas has checked that every updatable component is a <biasedlinearity>)
+      DpChunk &ch = dp_chunks_[dp_chunk_of_layer_[i]];
+      if (i != ch.layers.back()) return;
+      // The back-propagation of the chunk's lowest layer is queued: nothing on the main stream reads these
+      // weights any more.  Exchange stream: sum of the gradient shards, then the step on this rank's shard.
+      khStream_t xs = dev.AuxStream();
+      const size_t per_rank = (ch.end - ch.begin) / dp_ranks_;
+      const bool top = &ch == &dp_chunks_[0];
+      if (top) {
+        // gradients launched and marked in front of the back-propagation: a second mark behind it for the step
+        // (none where no back-propagation followed: the bottom layer of a pass without an input gradient)
+        const bool bp_followed = !(i == 0 && out_err == NULL);
+        if (bp_followed) CU_SAFE_CALL(hipK_event_record(ch.weights_read, dev.MainStream()));
+        CU_SAFE_CALL(hipK_stream_wait_event(xs, ch.grad_ready));
+        CU_SAFE_CALL(hipF_reduce_scatter_sum(xs, dp_g_arena_ + ch.begin, per_rank));
+        if (bp_followed) CU_SAFE_CALL(hipK_stream_wait_event(xs, ch.weights_read));
+      } else {
+        {
+          CuProfileScope p("BiasedLinearity::ComputeGradient");
+          CU_SAFE_CALL(hipF_affine_gradient_group(dev.MainStream(), static_cast<int32>(dp_grad_items_.size()), &dp_grad_items_[0]));
+          dp_grad_items_.clear();
+        }
+        CU_SAFE_CALL(hipK_event_record(ch.grad_ready, dev.MainStream()));
+        CU_SAFE_CALL(hipK_stream_wait_event(xs, ch.grad_ready));
+        CU_SAFE_CALL(hipF_reduce_scatter_sum(xs, dp_g_arena_ + ch.begin, per_rank));
+      }
+      khSgdSegment segs[KH_MAX_SGD_SEGMENTS];
+      int32 nseg = 0;
+      for (size_t k = 0; k < ch.layers.size(); ++k) {  // (ascending offsets)
+        BiasedLinearity *bl = static_cast<BiasedLinearity *>(nnet_[ch.layers[k]]);
+        if (!(bl->GetLearnRate() > 0.0)) continue;  // (the reference skips the update of such a layer)
+        bl->DescribeStep(ch.offsets[k], total_frames, &segs[nseg], &segs[nseg + 1]);
+        nseg += 2;
+      }
+      size_t first = 0, count = 0;
+      CU_SAFE_CALL(hipK_comm_shard_range(per_rank, &first, &count));
+      CU_SAFE_CALL(hipF_sgd_apply_segments(xs, nseg, segs, ch.begin + first, count, dp_g_arena_, dp_w_arena_, dp_c_arena_));
+      aux_used = true;
+      return;
+    }
     if (overlap && dp_ranks_ > 1 && nnet_[i]->IsUpdatable() && nnet_[i]->GetType() == Component::kBiasedLinearity) {
       weights_read(i);
       const PendingUpdate pu = {i, &input, &err};
@@ -385,14 +448,14 @@ void Nnet::Backpropagate(const CuMatrix<BaseFloat> &in_err, CuMatrix<BaseFloat> 
       // this layer and the sigmoid below it in one step; y = propagate_buf_[i] is that sigmoid's output
       BiasedLinearity *bl = static_cast<BiasedLinearity *>(comp);
       CuMatrix<BaseFloat> *below2 = (i - 1 > 0) ? &backpropagate_buf_[i - 2] : out_err;
-      err_ready(i);
+      err_ready(i, propagate_buf_[i], *err);
       if (below2 != NULL) bl->BackpropagateFused(*err, propagate_buf_[i], below2);
       update_or_defer(i, propagate_buf_[i], *err);
       err = below2;
       i -= 2;
       continue;
     }
-    err_ready(i);
+    err_ready(i, propagate_buf_[i], *err);
     if (below != NULL) comp->Backpropagate(*err, below);
     update_or_defer(i, propagate_buf_[i], *err);
     err = below;
@@ -407,8 +470,158 @@ void Nnet::Backpropagate(const CuMatrix<BaseFloat> &in_err, CuMatrix<BaseFloat> 
     for (size_t k = 0; k < deferred_layers_.size(); ++k)
       static_cast<BiasedLinearity *>(nnet_[deferred_layers_[k]])->AfterGroupedUpdate();
   }
+  if (arena) {
+    // The new weights, bottom-up: the next forward pass needs the lowest layers first and waits per chunk
+    // (WaitForLayerWeights); nothing here is joined into the main stream.
+    khStream_t xs = dev.AuxStream();
+    for (size_t c = dp_chunks_.size(); c-- > 0;) {
+      DpChunk &ch = dp_chunks_[c];
+      CU_SAFE_CALL(hipF_allgather_shards(xs, dp_w_arena_ + ch.begin, (ch.end - ch.begin) / dp_ranks_));
+      {
+        CuStreamScope scope(xs);
+        for (size_t k = 0; k < ch.layers.size(); ++k) static_cast<BiasedLinearity *>(nnet_[ch.layers[k]])->FinishShardedStep();
+      }
+      CU_SAFE_CALL(hipK_event_record(ch.weights_ready, xs));
+      ch.pending = true;
+    }
+    if (side_used) dev.Order(dev.SideStream(), dev.MainStream(), &join_event_);
+    return;
+  }
   if (side_used) dev.Order(dev.SideStream(), dev.MainStream(), &join_event_);
   if (aux_used) dev.Order(dev.AuxStream(), dev.MainStream(), &aux_join_event_);
+}
+
+void Nnet::WaitForLayerWeights(int32 i) {
+  if (dp_chunk_of_layer_.empty() || dp_chunk_of_layer_[i] < 0) return;
+  DpChunk &ch = dp_chunks_[dp_chunk_of_layer_[i]];
+  if (!ch.pending) return;
+  CU_SAFE_CALL(hipK_stream_wait_event(CuDevice::Instantiate().MainStream(), ch.weights_ready));
+  ch.pending = false;
+}
+
+void Nnet::FinishExchange() {
+  for (size_t c = 0; c < dp_chunks_.size(); ++c) {
+    if (!dp_chunks_[c].pending) continue;
+    CU_SAFE_CALL(hipK_stream_wait_event(CuDevice::Instantiate().MainStream(), dp_chunks_[c].weights_ready));
+    dp_chunks_[c].pending = false;
+  }
+}
+
+bool Nnet::SetupArenas() {
+  if (dp_w_arena_ != NULL) return true;
+  if (dp_arena_failed_) return false;
+  // the <biasedlinearity> layers, top-down; anything else that is updatable, or an L1 penalty, rules the arenas out
+  std::vector<int32> layers;
+  size_t total = 0;
+  for (int32 i = LayerCount() - 1; i >= 0; --i) {
+    if (!nnet_[i]->IsUpdatable()) continue;
+    if (nnet_[i]->GetType() != Component::kBiasedLinearity || !static_cast<BiasedLinearity *>(nnet_[i])->CanUseArena()) {
+      dp_arena_failed_ = true;
+      return false;
+    }
+    layers.push_back(i);
+    total += static_cast<BiasedLinearity *>(nnet_[i])->ParameterSpan();
+  }
+  if (layers.empty()) {
+    dp_arena_failed_ = true;
+    return false;
+  }
+  // Chunks of roughly equal size, cut top-down (the output layer of a large net is a chunk of its own): few
+  // enough that the host queues a handful of collectives per step, enough that the first sums travel while the
+  // back-propagation is still running.  KALDI_AMD_DP_CHUNKS overrides the number (1: one exchange behind the pass).
+  int32 nchunks = 3;
+  if (const char *e = getenv("KALDI_AMD_DP_CHUNKS")) nchunks = atoi(e);
+  if (nchunks < 1) nchunks = 1;
+  if (nchunks > static_cast<int32>(layers.size())) nchunks = layers.size();
+  const size_t quantum = static_cast<size_t>(dp_ranks_) * 64;  // every shard a whole number of 256-byte lines
+  dp_chunks_.clear();
+  dp_chunk_of_layer_.assign(LayerCount(), -1);
+  size_t pos = 0, in_chunk = 0;
+  dp_chunks_.push_back(DpChunk());
+  for (size_t k = 0; k < layers.size(); ++k) {
+    BiasedLinearity *bl = static_cast<BiasedLinearity *>(nnet_[layers[k]]);
+    if (in_chunk > 0 && in_chunk >= total / nchunks && static_cast<int32>(dp_chunks_.size()) < nchunks) {
+      pos = (pos + quantum - 1) / quantum * quantum;
+      dp_chunks_.back().end = pos;
+      dp_chunks_.push_back(DpChunk());
+      dp_chunks_.back().begin = pos;
+      in_chunk = 0;
+    }
+    // (top-down in the pass, but ascending addresses bottom-up inside the chunk are not needed: any order does)
+    dp_chunks_.back().layers.push_back(layers[k]);
+    dp_chunks_.back().offsets.push_back(pos);
+    dp_chunk_of_layer_[layers[k]] = dp_chunks_.size() - 1;
+    pos += bl->ParameterSpan();
+    in_chunk += bl->ParameterSpan();
+  }
+  pos = (pos + quantum - 1) / quantum * quantum;
+  dp_chunks_.back().end = pos;
+  dp_arena_floats_ = pos;
+  for (size_t c = 0; c < dp_chunks_.size(); ++c) {
+    KALDI_ASSERT(2 * dp_chunks_[c].layers.size() <= KH_MAX_SGD_SEGMENTS);
+    CU_SAFE_CALL(hipK_event_create_ordering(&dp_chunks_[c].grad_ready));
+    CU_SAFE_CALL(hipK_event_create_ordering(&dp_chunks_[c].weights_read));
+    CU_SAFE_CALL(hipK_event_create_ordering(&dp_chunks_[c].weights_ready));
+  }
+  CuDevice &dev = CuDevice::Instantiate();
+  void *p = NULL;
+  CU_SAFE_CALL(hipK_malloc(&p, dp_arena_floats_ * sizeof(BaseFloat)));
+  dp_w_arena_ = static_cast<BaseFloat *>(p);
+  CU_SAFE_CALL(hipK_malloc(&p, dp_arena_floats_ * sizeof(BaseFloat)));
+  dp_g_arena_ = static_cast<BaseFloat *>(p);
+  // (the padding of rows, biases and chunks stays zero for good: gradient 0, weight 0)
+  CU_SAFE_CALL(hipK_memset_async(dev.MainStream(), dp_w_arena_, 0, dp_arena_floats_ * sizeof(BaseFloat)));
+  CU_SAFE_CALL(hipK_memset_async(dev.MainStream(), dp_g_arena_, 0, dp_arena_floats_ * sizeof(BaseFloat)));
+  CuStreamScope scope(dev.MainStream());
+  for (size_t c = 0; c < dp_chunks_.size(); ++c)
+    for (size_t k = 0; k < dp_chunks_[c].layers.size(); ++k)
+      static_cast<BiasedLinearity *>(nnet_[dp_chunks_[c].layers[k]])->MoveParametersTo(dp_w_arena_ + dp_chunks_[c].offsets[k]);
+  return true;
+}
+
+void Nnet::EnsureCorrectionArena() {
+  if (dp_c_arena_ != NULL || dp_w_arena_ == NULL) return;
+  bool need = false;
+  for (size_t c = 0; c < dp_chunks_.size(); ++c)
+    for (size_t k = 0; k < dp_chunks_[c].layers.size(); ++k)
+      if (static_cast<BiasedLinearity *>(nnet_[dp_chunks_[c].layers[k]])->NeedsCorrections()) need = true;
+  if (!need) return;
+  CuDevice &dev = CuDevice::Instantiate();
+  void *p = NULL;
+  CU_SAFE_CALL(hipK_malloc(&p, dp_arena_floats_ * sizeof(BaseFloat)));
+  dp_c_arena_ = static_cast<BaseFloat *>(p);
+  CU_SAFE_CALL(hipK_memset_async(dev.MainStream(), dp_c_arena_, 0, dp_arena_floats_ * sizeof(BaseFloat)));
+  CuStreamScope scope(dev.MainStream());
+  for (size_t c = 0; c < dp_chunks_.size(); ++c)
+    for (size_t k = 0; k < dp_chunks_[c].layers.size(); ++k)
+      static_cast<BiasedLinearity *>(nnet_[dp_chunks_[c].layers[k]])->MoveCorrectionsTo(dp_c_arena_ + dp_chunks_[c].offsets[k]);
+  // the exchange stream uses the arena from the next step on
+  dev.Order(dev.MainStream(), dev.AuxStream(), &aux_join_event_);
+}
+
+void Nnet::ReleaseArenas() {
+  if (dp_w_arena_ == NULL) {
+    dp_arena_failed_ = false;
+    return;
+  }
+  FinishExchange();
+  CU_SAFE_CALL(hipK_device_synchronize());
+  for (size_t c = 0; c < dp_chunks_.size(); ++c) {
+    for (size_t k = 0; k < dp_chunks_[c].layers.size(); ++k)
+      static_cast<BiasedLinearity *>(nnet_[dp_chunks_[c].layers[k]])->OwnParametersAgain();
+    hipK_event_destroy(dp_chunks_[c].grad_ready);
+    hipK_event_destroy(dp_chunks_[c].weights_read);
+    hipK_event_destroy(dp_chunks_[c].weights_ready);
+  }
+  CU_SAFE_CALL(hipK_device_synchronize());
+  dp_chunks_.clear();
+  dp_chunk_of_layer_.clear();
+  CU_SAFE_CALL(hipK_free(dp_w_arena_));
+  CU_SAFE_CALL(hipK_free(dp_g_arena_));
+  if (dp_c_arena_) CU_SAFE_CALL(hipK_free(dp_c_arena_));
+  dp_w_arena_ = dp_g_arena_ = dp_c_arena_ = NULL;
+  dp_arena_floats_ = 0;
+  dp_arena_failed_ = false;
 }
 
 void Nnet::Feedforward(const CuMatrix<BaseFloat> &in, CuMatrix<BaseFloat> *out) {
@@ -419,6 +632,7 @@ void Nnet::Feedforward(const CuMatrix<BaseFloat> &in, CuMatrix<BaseFloat> *out) 
     return;
   }
   KALDI_ASSERT(propagate_buf_.size() >= 2 || L == 1);
+  FinishExchange();
   // steps: each is one component or a fused (linearity, activation) pair; intermediate results
   // alternate between the first two buffers, the last step writes into *out
   const CuMatrix<BaseFloat> *src = &in;
@@ -463,11 +677,13 @@ void Nnet::Write(const std::string &file, bool binary) {
 }
 
 void Nnet::Write(std::ostream &out, bool binary) {
+  FinishExchange();
   for (int32 i = 0; i < LayerCount(); ++i) nnet_[i]->Write(out, binary);
 }
 
 void Nnet::WriteFrontLayers(std::ostream &out, bool binary, int32 num_layers) {
   KALDI_ASSERT(num_layers <= LayerCount());
+  FinishExchange();
   for (int32 i = 0; i < num_layers; ++i) nnet_[i]->Write(out, binary);
 }
 
@@ -520,19 +736,23 @@ void Nnet::SetAverageGrad(bool flag) { KALDI_AMD_FOR_UPDATABLE(SetAverageGrad(fl
 
 void Nnet::SetDataParallel(int32 nranks) {
   KALDI_ASSERT(nranks >= 1);
+  ReleaseArenas();
   dp_ranks_ = nranks;
   // Three exchanges give the same step.
+  //  shard:  (the default) the parameters of the <biasedlinearity> layers live in arenas (SetupArenas), cut into a
+  //          few chunks of layers.  Per chunk: the gradients in one launch, a reduce-scatter of the chunk's
+  //          gradient memory, the step on this rank's 1/n of the chunk, and -- bottom-up behind the pass -- an
+  //          all-gather of the new parameters in place, for which the next forward pass waits layer by layer.
+  //          2(n-1)/n x 185 MB over the links per step of the Switchboard net, as for an all-reduce, but the
+  //          element-wise pass over gradient and weights is 1/n of the net per rank and the exchange runs beside
+  //          the back-propagation and the next forward pass.
   //  gather: every rank's rows of (layer input, layer error) are gathered -- (n-1) x 40 MB per rank and step on
   //          the Switchboard net at a 256-frame bunch -- and each rank runs the single-GPU fused update on the
   //          n x 256 rows (n times the update FLOPs, no gradient buffers, replicas identical by construction).
-  //  shard:  the per-layer gradients are summed by a reduce-scatter, each rank steps its 1/n of the layer and
-  //          the new weights are all-gathered in place: 2(n-1)/n x 185 MB over the links, as for an all-reduce,
-  //          but the post-exchange pass over gradient and weights shrinks to 1/n of the layer per rank.
-  //  sum:    all-reduce of the gradients, the whole step on every rank (kept for layers whose weight memory
-  //          does not cut evenly, and for comparison).
-  // Few ranks: gather; many: shard.
-  dp_gather_ = nranks >= 2 && nranks <= 4;
-  dp_shard_ = nranks > 4;
+  //  sum:    all-reduce of each layer's gradient, the whole step on every rank (also what a network takes that
+  //          cannot use the arenas: an L1 penalty, an updatable component of another kind).
+  dp_gather_ = false;
+  dp_shard_ = nranks >= 2;
   if (const char *e = getenv("KALDI_AMD_DP_EXCHANGE")) {
     dp_gather_ = nranks >= 2 && std::string(e) == "gather";
     dp_shard_ = nranks >= 2 && std::string(e) == "shard";

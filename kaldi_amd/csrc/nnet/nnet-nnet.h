@@ -49,7 +49,10 @@ class Nnet {
   MatrixIndexT InputDim() const;
   MatrixIndexT OutputDim() const;
   MatrixIndexT LayerCount() const { return nnet_.size(); }
-  Component *Layer(MatrixIndexT index) { return nnet_[index]; }
+  Component *Layer(MatrixIndexT index) {
+    FinishExchange();  // (the caller may be after the layer's parameters)
+    return nnet_[index];
+  }
   int IndexOfLayer(const Component &comp) const;
 
   const std::vector<CuMatrix<BaseFloat> > &PropagateBuffer() const { return propagate_buf_; }
@@ -89,12 +92,32 @@ class Nnet {
   /// exchange (see SetDataParallel's definition) is chosen by the number of ranks; the environment variable
   /// KALDI_AMD_DP_EXCHANGE = gather | shard | sum overrides it.
   void SetDataParallel(int32 nranks);
+  /// Sharded data-parallel training leaves the last step's exchange of new weights running beside whatever
+  /// the caller does next; the next Propagate waits layer by layer for what it needs.  Anything else that reads
+  /// parameters on the main stream calls this first (Write, Feedforward and Layer do): the main stream then
+  /// continues only behind the exchange.  No host wait; nothing to do otherwise.
+  void FinishExchange();
 
  private:
   typedef std::vector<Component *> NnetType;
   void UpdateLayer(int32 i, const CuMatrix<BaseFloat> &input, const CuMatrix<BaseFloat> &err);
   void DataParallelGradient(int32 i, class BiasedLinearity *bl, const CuMatrix<BaseFloat> &input,
                             const CuMatrix<BaseFloat> &err);
+
+  /// A run of <biasedlinearity> layers (top-down) whose parameters lie one after another in the arenas and are
+  /// exchanged together in the sharded data-parallel step.
+  struct DpChunk {
+    std::vector<int32> layers;    // component indices, top-down
+    std::vector<size_t> offsets;  // of each layer's parameters in the arenas (floats)
+    size_t begin, end;            // [begin, end) in the arenas; the length is a multiple of ranks * 64
+    khEvent_t grad_ready, weights_read, weights_ready;
+    bool pending;                 // weights_ready has been recorded and the main stream has not waited for it yet
+    DpChunk() : begin(0), end(0), grad_ready(NULL), weights_read(NULL), weights_ready(NULL), pending(false) {}
+  };
+  bool SetupArenas();
+  void ReleaseArenas();
+  void EnsureCorrectionArena();
+  void WaitForLayerWeights(int32 i);
 
   NnetType nnet_;
   std::vector<CuMatrix<BaseFloat> > propagate_buf_;
@@ -114,6 +137,13 @@ class Nnet {
   std::vector<BaseFloat *> dp_layer_grad_;  // data-parallel: one gradient buffer per layer
   std::vector<size_t> dp_layer_grad_size_;
   khEvent_t join_event_, aux_join_event_;
+  // sharded exchange: the parameter arenas (weights, gradients, momentum state: one layout) and their chunks
+  std::vector<DpChunk> dp_chunks_;
+  std::vector<int32> dp_chunk_of_layer_;
+  BaseFloat *dp_w_arena_ = NULL, *dp_g_arena_ = NULL, *dp_c_arena_ = NULL;
+  size_t dp_arena_floats_ = 0;
+  bool dp_arena_failed_ = false;  // this network cannot use the arenas (an L1 penalty, another updatable component)
+  std::vector<khAffineGradient> dp_grad_items_;
   bool group_updates_ = getenv("KALDI_AMD_NO_GROUP_UPDATES") == NULL;  // (the variable: for A/B measurements)
   std::vector<khAffineUpdate> deferred_updates_;  // the updates of this Backpropagate call, launched at its end
   std::vector<int32> deferred_layers_;

@@ -43,14 +43,53 @@ struct DistOptions {
   }
 };
 
-/// What tells this launch's id file from a stale one left by a launch that died: the launcher's run id where
-/// there is one (torch.distributed.run exports TORCHELASTIC_RUN_ID), the rendezvous port, and the parent
-/// process -- the ranks of one launch are children of one launcher, and a relaunch has another.
-inline std::string CommNonce() {
+/// What tells this launch's id file from a stale one left by a launch that died.  Where the launcher gives the
+/// launch a name -- KALDI_AMD_RUN_ID, else TORCHELASTIC_RUN_ID (exported by torch.distributed.run) -- the nonce is
+/// that name and the rendezvous port: the same on every node and in every shell.  Without a name the parent
+/// process id stands in for one: the ranks of one launch on one node are children of one launcher and a
+/// relaunch has another.  Ranks started by hand from several shells, or on several nodes without such a
+/// launcher, must therefore export a common KALDI_AMD_RUN_ID.
+inline std::string CommNonce(long parent_pid) {
   const char *run = getenv("KALDI_AMD_RUN_ID");
-  if (!run) run = getenv("TORCHELASTIC_RUN_ID");
+  if (!run || !*run) run = getenv("TORCHELASTIC_RUN_ID");
   const char *port = getenv("MASTER_PORT");
-  return std::string(run ? run : "-") + ":" + (port ? port : "-") + ":" + std::to_string(static_cast<long>(getppid()));
+  if (run && *run) return std::string(run) + ":" + (port ? port : "-");
+  return std::string("-:") + (port ? port : "-") + ":" + std::to_string(parent_pid);
+}
+inline std::string CommNonce() { return CommNonce(static_cast<long>(getppid())); }
+
+/// The id file: [8-byte magic | uint32 nonce length | nonce | id].  Written to a fresh file (O_EXCL, mode 0600)
+/// beside the final name and renamed into place, so a reader never sees half of it.
+inline bool WriteCommIdFile(const std::string &file, const std::string &nonce, const unsigned char *id, size_t id_bytes) {
+  static const char magic[8] = {'K', 'A', 'M', 'D', 'I', 'D', '0', '1'};
+  const std::string tmp = file + ".tmp." + std::to_string(static_cast<long>(getpid()));
+  unlink(file.c_str());  // whatever an earlier launch left
+  unlink(tmp.c_str());
+  const int fd = open(tmp.c_str(), O_WRONLY | O_CREAT | O_EXCL, 0600);
+  if (fd < 0) return false;
+  const uint32 n = nonce.size();
+  bool ok = write(fd, magic, sizeof(magic)) == static_cast<ssize_t>(sizeof(magic)) &&
+            write(fd, &n, sizeof(n)) == static_cast<ssize_t>(sizeof(n)) &&
+            write(fd, nonce.data(), n) == static_cast<ssize_t>(n) &&
+            write(fd, id, id_bytes) == static_cast<ssize_t>(id_bytes);
+  ok = (close(fd) == 0) && ok;
+  return ok && rename(tmp.c_str(), file.c_str()) == 0;
+}
+/// True when `file` is a complete id file that carries `nonce`; anything else (absent, short, another launch's)
+/// is "not yet".
+inline bool ReadCommIdFile(const std::string &file, const std::string &nonce, unsigned char *id, size_t id_bytes) {
+  static const char magic[8] = {'K', 'A', 'M', 'D', 'I', 'D', '0', '1'};
+  std::ifstream is(file.c_str(), std::ios::binary);
+  if (!is.good()) return false;
+  char m[8];
+  uint32 n = 0;
+  is.read(m, sizeof(m));
+  is.read(reinterpret_cast<char *>(&n), sizeof(n));
+  if (!is.good() || memcmp(m, magic, sizeof(m)) != 0 || n != nonce.size()) return false;
+  std::string got(n, '\0');
+  is.read(&got[0], n);
+  is.read(reinterpret_cast<char *>(id), id_bytes);
+  return is.gcount() == static_cast<std::streamsize>(id_bytes) && got == nonce;
 }
 
 /// selects the GPU and, with more than one rank and need_comm, builds the RCCL communicator
@@ -58,7 +97,8 @@ inline std::string CommNonce() {
 /// Rank 0 hands the RCCL id to the others through --comm-id-file: [magic | nonce | id], written to a fresh
 /// file (O_EXCL, mode 0600) and renamed into place; readers wait for a file that carries THEIR launch's nonce,
 /// so an id left behind by a killed launch is never joined.  For a multi-node run the file must be on storage
-/// every node sees, and ranks started by hand should be given a --comm-id-file of their own per launch.
+/// every node sees and the ranks need a common run id (see CommNonce); ranks started by hand should also be
+/// given a --comm-id-file of their own per launch.
 inline void DistInit(const DistOptions &o, bool need_comm = true) {
   CuDevice::Instantiate().SelectGpuId(o.gpu_id);
   if (o.num_ranks == 1 || !need_comm) return;
@@ -69,42 +109,20 @@ inline void DistInit(const DistOptions &o, bool need_comm = true) {
     return;
   }
   unsigned char id[KH_COMM_ID_BYTES];
-  const std::string tmp = o.comm_id_file + ".tmp." + std::to_string(static_cast<long>(getpid()));
   const std::string nonce = CommNonce();
-  const char magic[8] = {'K', 'A', 'M', 'D', 'I', 'D', '0', '1'};
   if (o.rank == 0) {
-    unlink(o.comm_id_file.c_str());  // whatever an earlier launch left
-    unlink(tmp.c_str());
     CU_SAFE_CALL(hipK_comm_get_unique_id(id));
-    const int fd = open(tmp.c_str(), O_WRONLY | O_CREAT | O_EXCL, 0600);
-    if (fd < 0) KALDI_ERR << "Cannot create " << tmp << " for the communicator id";
-    const uint32 n = nonce.size();
-    bool ok = write(fd, magic, sizeof(magic)) == static_cast<ssize_t>(sizeof(magic)) &&
-              write(fd, &n, sizeof(n)) == static_cast<ssize_t>(sizeof(n)) &&
-              write(fd, nonce.data(), n) == static_cast<ssize_t>(n) &&
-              write(fd, id, sizeof(id)) == static_cast<ssize_t>(sizeof(id));
-    ok = (close(fd) == 0) && ok;
-    if (!ok || rename(tmp.c_str(), o.comm_id_file.c_str()) != 0)
+    if (!WriteCommIdFile(o.comm_id_file, nonce, id, sizeof(id)))
       KALDI_ERR << "Cannot write the communicator id to " << o.comm_id_file;
   } else {
     bool ok = false;
     for (int tries = 0; tries < 6000 && !ok; ++tries) {  // up to 10 minutes
-      std::ifstream is(o.comm_id_file.c_str(), std::ios::binary);
-      if (is.good()) {
-        char m[8];
-        uint32 n = 0;
-        is.read(m, sizeof(m));
-        is.read(reinterpret_cast<char *>(&n), sizeof(n));
-        if (is.good() && memcmp(m, magic, sizeof(m)) == 0 && n == nonce.size()) {
-          std::string got(n, '\0');
-          is.read(&got[0], n);
-          is.read(reinterpret_cast<char *>(id), sizeof(id));
-          ok = is.gcount() == static_cast<std::streamsize>(sizeof(id)) && got == nonce;  // else: a stale file
-        }
-      }
+      ok = ReadCommIdFile(o.comm_id_file, nonce, id, sizeof(id));
       if (!ok) usleep(100000);
     }
-    if (!ok) KALDI_ERR << "Timed out waiting for this launch's communicator id in " << o.comm_id_file;
+    if (!ok)
+      KALDI_ERR << "Timed out waiting for this launch's communicator id in " << o.comm_id_file
+                << " (ranks started from different shells or nodes must export a common KALDI_AMD_RUN_ID)";
   }
   CU_SAFE_CALL(hipK_comm_init(id, o.rank, o.num_ranks));
   CU_SAFE_CALL(hipK_comm_barrier(CuDevice::Instantiate().Stream()));

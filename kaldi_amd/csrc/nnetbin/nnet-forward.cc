@@ -111,7 +111,7 @@ int main(int argc, char *argv[]) {
     // shares its batch: one process and several ranks, which cut the table into different batches, write the same.
     // Only for networks whose every component treats the rows of its input one by one: a splice (<expand>) in the
     // model itself reaches into neighbouring frames, and <dropout> draws from a generator whose state is laid out
-    // by matrix size.  Such models run one utterance at a time, as before.
+    // by matrix size.  Such models run one utterance at a time, as before, with the same row-invariant products.
     bool rows_independent = true;
     for (int32 i = 0; i < nnet.LayerCount(); ++i) {
       const Component::ComponentType t = nnet.Layer(i)->GetType();
@@ -120,7 +120,8 @@ int main(int argc, char *argv[]) {
         rows_independent = false;
     }
     const bool batching = batch_frames > 1 && rows_independent;
-    if (batching) CU_SAFE_CALL(hipK_gemm_row_invariant(1));
+    // (also without batching: --batch-frames=0 and models that run one utterance at a time write the same bits)
+    CU_SAFE_CALL(hipK_gemm_row_invariant(1));
     CuMatrix<BaseFloat> batch_in, batch_view;
     int32 batch_rows = 0;
     auto finish_output = [&](CuMatrix<BaseFloat> *nnet_out) {

@@ -238,12 +238,20 @@ class PosteriorWriter {
         s = queue_.front();
         queue_.pop_front();
       }
-      try {
-        WriteOne(s);
-      } catch (...) {
-        hipK_event_synchronize(s->copied);  // the slot's memory must be idle before it is handed out again
-        std::lock_guard<std::mutex> l(mu_);
-        if (!error_) error_ = std::current_exception();
+      // After the first failure nothing more is written: the reference stops at the first bad utterance
+      // (nnetbin/nnet-forward.cc:116-156), so the table must not go on past a gap.  Within the failing slot
+      // WriteOne has written the utterances in front of the bad one, as the reference would have.
+      if (failed_) {
+        hipK_event_synchronize(s->copied);
+      } else {
+        try {
+          WriteOne(s);
+        } catch (...) {
+          hipK_event_synchronize(s->copied);  // the slot's memory must be idle before it is handed out again
+          std::lock_guard<std::mutex> l(mu_);
+          if (!error_) error_ = std::current_exception();
+          failed_ = true;
+        }
       }
       std::lock_guard<std::mutex> l(mu_);
       free_.push_back(s);
@@ -259,6 +267,7 @@ class PosteriorWriter {
   std::condition_variable cv_free_, cv_work_;
   std::deque<Slot *> free_, queue_;
   std::exception_ptr error_;
+  bool failed_ = false;  // written and read by the writer thread only
   bool stop_;
   std::thread thread_;
   KALDI_DISALLOW_COPY_AND_ASSIGN(PosteriorWriter);

@@ -66,12 +66,23 @@ class KaldiObjectHolder {
             t_.ReadBinaryPayload(is, tok, r, c);
             *payload_read += bytes;
           } else if (bytes > 0) {
+            // The skipped bytes must exist: a table cut off inside another rank's entry is as truncated for this
+            // rank as for the one that reads it.  A seek past the end of a file succeeds, so the last skipped byte
+            // is read; a discard that runs into the end of a pipe sets only eofbit, so its count is checked.
             const std::istream::pos_type here = is.tellg();
             if (here != std::istream::pos_type(-1)) {
-              is.seekg(here + bytes);
+              is.seekg(here + (bytes - 1));
+              if (is.fail() || is.get() == std::istream::traits_type::eof()) {
+                KALDI_WARN << "Reading Table object, truncated inside a skipped entry";
+                return false;
+              }
             } else {
               is.clear();
               is.ignore(bytes);  // not seekable: the bytes have to pass through anyway
+              if (is.gcount() != bytes) {
+                KALDI_WARN << "Reading Table object, truncated inside a skipped entry";
+                return false;
+              }
               *payload_read += bytes;
             }
             if (is.fail()) return false;

@@ -32,6 +32,19 @@ class AffineUpdate(ctypes.Structure):
                 ("corr", ctypes.c_void_p), ("ldcorr", ctypes.c_int32), ("bias", ctypes.c_void_p), ("bcorr", ctypes.c_void_p)]
 
 
+class AffineGradient(ctypes.Structure):
+    """khAffineGradient: one item of hipF_affine_gradient_group."""
+    _fields_ = [("N", ctypes.c_int32), ("O", ctypes.c_int32), ("I", ctypes.c_int32),
+                ("e", ctypes.c_void_p), ("lde", ctypes.c_int32), ("in_", ctypes.c_void_p), ("ldin", ctypes.c_int32),
+                ("gW", ctypes.c_void_p), ("ldg", ctypes.c_int32), ("gb", ctypes.c_void_p)]
+
+
+class SgdSegment(ctypes.Structure):
+    """khSgdSegment: one run of elements of hipF_sgd_apply_segments with its hyper-parameters."""
+    _fields_ = [("begin", ctypes.c_size_t), ("end", ctypes.c_size_t), ("gscale", ctypes.c_float),
+                ("momentum", ctypes.c_float), ("lr", ctypes.c_float), ("l2", ctypes.c_float)]
+
+
 _CTYPES = {
     "int": ctypes.c_int, "int32_t": ctypes.c_int32, "float": ctypes.c_float, "size_t": ctypes.c_size_t,
     "khStream_t": ctypes.c_void_p, "khEvent_t": ctypes.c_void_p, "MatrixDim": MatrixDim,

@@ -41,6 +41,10 @@ _SIGS = {
     "nnet1_synchronize": (I, []),
     "nnet1_shard_assign": (I, [I, I, P, P]),
     "nnet1_substitute_job": (I, [ctypes.c_char_p, I, ctypes.c_char_p, I]),
+    "nnet1_table_scan_shard": (I, [ctypes.c_char_p, I, I, P, P, P]),
+    "nnet1_comm_nonce": (I, [ctypes.c_long, ctypes.c_char_p, I]),
+    "nnet1_comm_id_file_write": (I, [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, I]),
+    "nnet1_comm_id_file_read": (I, [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, I]),
 }
 for _n, (_r, _a) in _SIGS.items():
     _f = getattr(lib, _n)
@@ -164,6 +168,34 @@ def substitute_job(spec, rank):
     buf = ctypes.create_string_buffer(len(spec) + 32)
     _check(lib.nnet1_substitute_job(spec.encode(), rank, buf, len(buf)))
     return buf.value.decode()
+
+
+def table_scan_shard(rspecifier, num_ranks, rank):
+    """(entries kept, frames kept, payload bytes read) of rank `rank` walking a float-matrix table the way the
+    sharded nnet-forward does; raises NnetError on a read error (host only)."""
+    k, f, b = ctypes.c_longlong(), ctypes.c_longlong(), ctypes.c_longlong()
+    _check(lib.nnet1_table_scan_shard(rspecifier.encode(), num_ranks, rank, ctypes.byref(k), ctypes.byref(f), ctypes.byref(b)))
+    return k.value, f.value, b.value
+
+
+def comm_nonce(parent_pid):
+    """The launch nonce of the RCCL id file as a rank with this parent process computes it (host only)."""
+    buf = ctypes.create_string_buffer(512)
+    _check(lib.nnet1_comm_nonce(parent_pid, buf, len(buf)))
+    return buf.value.decode()
+
+
+def comm_id_file_write(path, nonce, ident):
+    _check(lib.nnet1_comm_id_file_write(path.encode(), nonce.encode(), bytes(ident), len(ident)))
+
+
+def comm_id_file_read(path, nonce, id_bytes):
+    """The id if `path` is a complete id file of the launch `nonce`, else None."""
+    buf = ctypes.create_string_buffer(id_bytes)
+    rc = lib.nnet1_comm_id_file_read(path.encode(), nonce.encode(), buf, id_bytes)
+    if rc < 0:
+        raise NnetError("comm_id_file_read: bad arguments")
+    return buf.raw if rc == 1 else None
 
 
 def synchronize():

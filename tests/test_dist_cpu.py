@@ -217,3 +217,75 @@ def test_shard_rule_and_job_substitution():
     assert nn.substitute_job("ark:out.JOB.ark", 2) == "ark:out.3.ark"
     assert nn.substitute_job("ark,scp:a.JOB.ark,a.JOB.scp", 0) == "ark,scp:a.1.ark,a.1.scp"
     assert nn.substitute_job("ark:plain.ark", 5) == "ark:plain.ark"
+
+
+def test_comm_nonce_and_id_file(tmp_path, monkeypatch):
+    """The RCCL id file of the tools (nnetbin/dist-utils.h): with a run id the nonce is the same whatever the
+    parent process (ranks on other nodes, ranks started from several shells); without one the parent pid
+    separates launches; a reader accepts only a complete file that carries its own launch's nonce."""
+    import kaldi_amd.nnet as nn
+    for var in ("KALDI_AMD_RUN_ID", "TORCHELASTIC_RUN_ID", "MASTER_PORT"):
+        monkeypatch.delenv(var, raising=False)
+    # no run id: the parent process is the launch
+    assert nn.comm_nonce(100) != nn.comm_nonce(200)
+    assert nn.comm_nonce(100) == "-:-:100"
+    monkeypatch.setenv("MASTER_PORT", "29512")
+    assert nn.comm_nonce(100) == "-:29512:100"
+    # a launcher's run id: the same nonce under different parents
+    monkeypatch.setenv("TORCHELASTIC_RUN_ID", "elastic7")
+    assert nn.comm_nonce(100) == nn.comm_nonce(200) == "elastic7:29512"
+    # KALDI_AMD_RUN_ID wins over the launcher's
+    monkeypatch.setenv("KALDI_AMD_RUN_ID", "byhand")
+    assert nn.comm_nonce(1) == nn.comm_nonce(99999) == "byhand:29512"
+
+    path = str(tmp_path / "comm_id")
+    ident = bytes(range(128))
+    assert nn.comm_id_file_read(path, "byhand:29512", 128) is None            # absent: not yet
+    nn.comm_id_file_write(path, "byhand:29512", ident)
+    assert nn.comm_id_file_read(path, "byhand:29512", 128) == ident
+    assert nn.comm_id_file_read(path, "other:29512", 128) is None             # another launch's file
+    assert nn.comm_id_file_read(path, "byhand:2951", 128) is None
+    assert (os.stat(path).st_mode & 0o777) == 0o600
+    # a stale file is replaced, a truncated one is "not yet"
+    nn.comm_id_file_write(path, "next:1", ident[::-1])
+    assert nn.comm_id_file_read(path, "byhand:29512", 128) is None
+    assert nn.comm_id_file_read(path, "next:1", 128) == ident[::-1]
+    whole = open(path, "rb").read()
+    open(path, "wb").write(whole[:-5])
+    assert nn.comm_id_file_read(path, "next:1", 128) is None
+
+
+def test_sharded_table_read_detects_truncation_inside_a_skipped_entry(tmp_path):
+    """Every rank of the sharded nnet-forward walks the same archive and skips the payload of other ranks'
+    utterances unread.  A table cut off inside an entry must be an error on EVERY rank -- also on the ranks that
+    skip that entry -- on a file (seek) and on a pipe (discard), like an unfiltered read of the same table."""
+    import kaldi_amd.nnet as nn
+    rs = np.random.RandomState(5)
+    lens = [30, 20, 10, 25, 15, 40]
+    utts = [("utt%d" % i, rs.standard_normal((n, 7)).astype(f32)) for i, n in enumerate(lens)]
+    whole = O.write_matrix_ark(utts)
+    ark = str(tmp_path / "feats.ark")
+    open(ark, "wb").write(whole)
+    owner = nn.shard_assign(2, lens).tolist()
+    per_utt = [n * 7 * 4 for n in lens]
+    for spec in ("ark:" + ark, "ark:cat %s |" % ark):
+        tot_kept = 0
+        for rank in (0, 1):
+            kept, frames, payload = nn.table_scan_shard(spec, 2, rank)
+            mine = [i for i, r in enumerate(owner) if r == rank]
+            assert kept == len(mine) and frames == sum(lens[i] for i in mine)
+            if spec.endswith("|"):
+                assert payload == sum(per_utt)                       # a pipe cannot be skipped, only discarded
+            else:
+                assert payload == sum(per_utt[i] for i in mine)      # a file: only the own payload is read
+            tot_kept += kept
+        assert tot_kept == len(lens)
+    # cut the archive inside the last entry's payload: the rank that skips it must fail like the one that owns it
+    cut = str(tmp_path / "cut.ark")
+    open(cut, "wb").write(whole[:-40])
+    for spec in ("ark:" + cut, "ark:cat %s |" % cut):
+        for rank in (0, 1):
+            with pytest.raises(nn.NnetError):
+                nn.table_scan_shard(spec, 2, rank)
+        with pytest.raises(nn.NnetError):
+            nn.table_scan_shard(spec, 1, 0)

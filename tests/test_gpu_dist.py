@@ -217,8 +217,8 @@ def test_data_parallel_three_steps_rm_shape_equal_oracle_on_stacked_bunch(hip, n
 def test_sharded_exchange_gives_the_bits_of_the_summed_one(hip, nn, tmp_path, monkeypatch, R):
     """KALDI_AMD_DP_EXCHANGE=shard (reduce-scatter, step on the own shard, all-gather of the new weights) against
     =sum (all-reduce, whole step everywhere): same weights, biases and momentum state bit for bit after three steps
-    with momentum, weight decay and the row-norm bound.  With 5 stand-in ranks two of the three layers do not cut
-    evenly and take the summed form inside a sharded run."""
+    with momentum, weight decay and the row-norm bound.  With 5 stand-in ranks no layer cuts evenly: the chunks of
+    the parameter arena are padded to a whole number of 256-byte lines per rank."""
     rs = np.random.RandomState(77)
     dims = [40, 96, 64, 33]
     data, _ = _model_bytes(rs, dims)
@@ -254,3 +254,102 @@ def test_rccl_entry_points_with_one_rank(nn):
     r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "rccl_probe.py")], stdout=subprocess.PIPE,
                        stderr=subprocess.STDOUT, timeout=110)
     assert r.returncode == 0 and b"rccl probe ok" in r.stdout, r.stdout.decode()[-2000:]
+
+
+def _swbd_layers(seed):
+    rs = np.random.RandomState(seed)
+    dims = [1320] + [2048] * 7 + [9000]
+    layers = []
+    for i in range(len(dims) - 1):
+        last = i == len(dims) - 2
+        layers.append(O.BiasedLinearity((0.1 * rs.standard_normal((dims[i + 1], dims[i]))).astype(f32),
+                                        np.zeros(dims[i + 1], f32) if last else (-4.1 + 0.2 * rs.random_sample(dims[i + 1])).astype(f32)))
+        layers.append(O.Softmax(dims[i + 1]) if last else O.Sigmoid(dims[i + 1]))
+    return dims, layers, rs
+
+
+def test_data_parallel_two_steps_swbd_shape_equal_oracle_on_stacked_bunch(hip, nn, tmp_path, monkeypatch):
+    """The data-parallel step at the size it is built for: the Switchboard-sized network (1320 -> 7 x 2048 -> 9000),
+    two stand-in ranks with a 256-frame bunch each, two steps with momentum, every exchange -- against the numpy
+    oracle on the stacked 512-row bunch (weights and biases of all eight layers), and the three exchanges against
+    each other: shard and sum bit for bit (one gradient kernel, one element-wise formula), gather to rounding
+    (it sums the 512 rows in one product)."""
+    dims, layers, rs = _swbd_layers(2031)
+    N, R, lr, mom, steps = 256, 2, 0.008, 0.5, 2
+    model = tmp_path / "m.nnet"
+    model.write_bytes(O.write_nnet(layers, True))
+    X = rs.standard_normal((steps, N, dims[0])).astype(f32)
+    T = rs.randint(0, dims[-1], (steps, N)).astype(np.int32)
+    net = O.Nnet(layers)
+    net.set_train_opts(lr, momentum=mom, average_grad=False)
+    xent = O.Xent()
+    for s in range(steps):
+        diff, _, _, _ = xent.eval_vec(net.propagate(np.concatenate([X[s]] * R)), np.concatenate([T[s]] * R))
+        net.backpropagate(diff)
+    got = {}
+    hip.call("hipK_comm_init_loopback", R)
+    try:
+        for exchange in ("shard", "sum", "gather"):
+            monkeypatch.setenv("KALDI_AMD_DP_EXCHANGE", exchange)
+            dp = nn.Trainer(str(model))
+            dp.set_train_opts(lr, mom, 0.0, 0.0, 0.0, False, True)
+            dp.set_data_parallel(R)
+            for s in range(steps):
+                x, t = hip.DevMatrix.from_numpy(X[s]), hip.DevMatrix.from_numpy(T[s], pitched=False)
+                dp.train_bunch(x.ptr, x.stride, N, dims[0], t.ptr)
+            frames, _, loss = dp.stats()
+            assert frames == steps * N
+            got[exchange] = [dp.layer_params(i, dims[i // 2 + 1], dims[i // 2]) for i in range(0, 2 * (len(dims) - 1), 2)]
+            dp.close()
+            # (the loss of the rank's own rows: half of the stacked bunch's)
+            assert abs(loss - xent.loss / R) < 1e-3 * abs(xent.loss / R), exchange
+    finally:
+        hip.call("hipK_comm_destroy")
+    for exchange, params in got.items():
+        for k, (W, b) in enumerate(params):
+            ref = net.layers[2 * k]
+            np.testing.assert_allclose(W, ref.W, rtol=1e-3, atol=2e-6 * np.abs(ref.W).max(), err_msg="%s layer %d" % (exchange, k))
+            np.testing.assert_allclose(b, ref.b, rtol=1e-3, atol=2e-6 * max(np.abs(ref.b).max(), 1e-3), err_msg="%s layer %d" % (exchange, k))
+    for (Wa, ba), (Wb, bb) in zip(got["shard"], got["sum"]):
+        assert np.array_equal(Wa, Wb) and np.array_equal(ba, bb)
+
+
+def test_forward_sharded_over_eight_ranks_swbd_shape_equals_single(hip, nn, tmp_path):
+    """nnet-forward --num-ranks=8 on the Switchboard-sized network: eight rank processes share the GPU (the path
+    has no collective), 44 utterances of 20..160 frames.  The union of their outputs equals the single-process
+    archive bit for bit -- the ranks cut the table into other batches than one process does, and the row-invariant
+    products make that invisible -- every utterance sits with the rank the rule names, and the ranks read the
+    feature payload exactly once between them."""
+    dims, layers, rs = _swbd_layers(2032)
+    (tmp_path / "m.nnet").write_bytes(O.write_nnet(layers, True))
+    lens = [int(n) for n in rs.randint(20, 161, 44)]
+    utts = [("utt%02d" % i, rs.standard_normal((n, dims[0])).astype(f32)) for i, n in enumerate(lens)]
+    (tmp_path / "f.ark").write_bytes(O.write_matrix_ark(utts))
+    exe = os.path.join(nn.BIN_DIR, "nnet-forward")
+    R = 8
+    r = subprocess.run([exe, "--silent=true", str(tmp_path / "m.nnet"), "ark:" + str(tmp_path / "f.ark"),
+                        "ark:" + str(tmp_path / "single.ark")], stderr=subprocess.PIPE, timeout=110)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    single = dict(O.read_matrix_ark((tmp_path / "single.ark").read_bytes()))
+    assert len(single) == len(utts)
+    procs = [subprocess.Popen([exe, "--num-ranks=%d" % R, "--rank=%d" % k, "--gpu-id=0", "--batch-frames=512", str(tmp_path / "m.nnet"),
+                               "ark:" + str(tmp_path / "f.ark"), "ark:" + str(tmp_path / "shard.JOB.ark")], stderr=subprocess.PIPE)
+             for k in range(R)]
+    read = []
+    for p in procs:
+        _, err = p.communicate(timeout=115)
+        assert p.returncode == 0, err.decode()[-2000:]
+        read.append(int(re.search(r"feature payload read (\d+) bytes", err.decode()).group(1)))
+    want = nn.shard_assign(R, lens)
+    shards = [dict(O.read_matrix_ark((tmp_path / ("shard.%d.ark" % (k + 1))).read_bytes())) for k in range(R)]
+    assert sum(len(s) for s in shards) == len(utts)
+    for i, (k, _) in enumerate(utts):
+        assert k in shards[want[i]]
+        np.testing.assert_array_equal(shards[want[i]][k], single[k])
+    payload = [n * dims[0] * 4 for n in lens]
+    assert sum(read) == sum(payload)
+    for k in range(R):
+        assert read[k] == sum(b for b, w in zip(payload, want) if w == k)
+    # one oracle check on top of the bit-equality: a short utterance's posteriors
+    i = int(np.argmin(lens))
+    np.testing.assert_allclose(single[utts[i][0]], O.Nnet(layers).feedforward(utts[i][1]), rtol=1e-4, atol=1e-9)

@@ -569,6 +569,92 @@ def test_affine_update_group_equals_single_launches(hip, mom):
         assert np.array_equal(s["Wb"].numpy(), w)
 
 
+def test_affine_gradient_group_and_sgd_apply_segments(hip):
+    """The two halves of the sharded data-parallel step.
+    hipF_affine_gradient_group: gW = e^T * in with the weight matrix's row pitch and gb = colsum(e) for several layers in
+    one launch -- against float64 numpy, bit for bit against the same items launched one at a time (another tile size
+    above the big-tile threshold, K summed in one piece either way), the row padding left alone; an item with dense
+    rows of 33 floats takes the stand-alone kernels inside the call.
+    hipF_sgd_apply_segments: the step on a range of an arena that holds those layers (weights, bias, padding) -- bit
+    for bit hipF_affine_apply layer by layer, elements outside the range or outside every segment untouched."""
+    import ctypes
+    h = hip
+    shapes = [(256, 2048, 1320), (256, 2048, 2048), (256, 1483, 1024), (37, 50, 24), (300, 130, 72), (16, 17, 33), (256, 9000, 2048)]
+    sets, items = [], (h.AffineGradient * len(shapes))()
+    for k, (N, O_, I) in enumerate(shapes):
+        x, e = rnd((N, I), 570 + k), rnd((N, O_), 590 + k, 0.01)
+        pitched = (N, O_, I) != (16, 17, 33)
+        dx, de = h.DevMatrix.from_numpy(x, pitched), h.DevMatrix.from_numpy(e, pitched)
+        ga, gb_ = h.DevMatrix.from_numpy(np.full((O_, I), 7.0, f32), pitched), h.DevMatrix.from_numpy(np.full((O_, I), 7.0, f32), pitched)
+        if pitched and ga.stride > I:   # mark the padding: it must come back untouched
+            h.call("hipF_set_const", None, ga.ptr, f32(-3.0), h.MatrixDim(O_, ga.stride, ga.stride))
+            h.call("hipF_set_const", None, gb_.ptr, f32(-3.0), h.MatrixDim(O_, gb_.stride, gb_.stride))
+        ba, bb = dev(h, np.zeros(O_, f32), False), dev(h, np.zeros(O_, f32), False)
+        sets.append(dict(N=N, O=O_, I=I, x=x, e=e, dx=dx, de=de, ga=ga, gb=gb_, ba=ba, bb=bb))
+        items[k] = h.AffineGradient(N, O_, I, de._p.value, de.stride, dx._p.value, dx.stride, ga._p.value, ga.stride, ba._p.value)
+    h.call("hipF_affine_gradient_group", None, 0, None)
+    h.call("hipF_affine_gradient_group", None, len(sets), ctypes.cast(items, ctypes.c_void_p))
+    for k, s_ in enumerate(sets):
+        one = (h.AffineGradient * 1)(h.AffineGradient(s_["N"], s_["O"], s_["I"], s_["de"]._p.value, s_["de"].stride, s_["dx"]._p.value,
+                                                      s_["dx"].stride, s_["gb"]._p.value, s_["gb"].stride, s_["bb"]._p.value))
+        h.call("hipF_affine_gradient_group", None, 1, ctypes.cast(one, ctypes.c_void_p))
+        G, G1 = s_["ga"].numpy(), s_["gb"].numpy()
+        ref = s_["e"].astype(np.float64).T @ s_["x"].astype(np.float64)
+        scale = np.abs(s_["e"]).max() * np.abs(s_["x"]).max()
+        np.testing.assert_allclose(G, ref, rtol=0, atol=6e-6 * np.sqrt(s_["N"]) * scale * 4)
+        assert np.array_equal(G, G1), shapes[k]
+        np.testing.assert_allclose(s_["ba"].numpy()[0], s_["e"].astype(np.float64).sum(0), rtol=1e-5, atol=1e-6)
+        assert np.array_equal(s_["ba"].numpy(), s_["bb"].numpy()), shapes[k]
+        if s_["ga"].stride > s_["I"] and shapes[k] != (16, 17, 33):
+            raw = np.zeros((s_["O"], s_["ga"].stride), f32)
+            h.call("hipK_memcpy", None, raw.ctypes.data, s_["ga"].ptr, raw.nbytes, 1)
+            assert np.all(raw[:, s_["I"]:] == -3.0), shapes[k]
+    items[len(sets) - 1].ldg = 1
+    with pytest.raises(h.HipError):
+        h.call("hipF_affine_gradient_group", None, len(sets), ctypes.cast(items, ctypes.c_void_p))
+
+    # ---- the step on an arena of three layers ---------------------------------------------------------------------
+    layers = [(96, 40), (64, 96), (33, 64)]
+    hyper = [(1.0 / 64, 0.7, 0.05, 1e-3), (1.0 / 64, 0.7, 0.025, 0.0), (1.0, 0.0, 0.01, 2e-3)]   # gscale, momentum, lr, l2
+    spans, off = [], 0
+    for O_, I in layers:
+        stride = (I * 4 + 255) // 256 * 64
+        spans.append((off, stride))
+        off += O_ * stride + (O_ + 63) // 64 * 64
+    total = (off + 511) // 512 * 512
+    rs = np.random.RandomState(99)
+    Wa, Ga, Ca = np.zeros(total, f32), np.zeros(total, f32), np.zeros(total, f32)
+    for (O_, I), (o, stride) in zip(layers, spans):
+        for arr, sc in ((Wa, 0.1), (Ga, 1.0), (Ca, 0.01)):
+            m = arr[o:o + O_ * stride].reshape(O_, stride)
+            m[:, :I] = sc * rs.standard_normal((O_, I))
+            arr[o + O_ * stride:o + O_ * stride + O_] = sc * rs.standard_normal(O_)
+    segs = (h.SgdSegment * 6)()
+    for k, ((O_, I), (o, stride), (g, mom, lr, l2)) in enumerate(zip(layers, spans, hyper)):
+        segs[2 * k] = h.SgdSegment(o, o + O_ * stride, g, mom, lr, l2)
+        segs[2 * k + 1] = h.SgdSegment(o + O_ * stride, o + O_ * stride + (O_ + 63) // 64 * 64, g, mom, lr, 0.0)
+    for first, count in ((0, total), (total // 4, total // 2), (total - 512, 512), (128, 0)):
+        dW, dG, dC = dev(h, Wa, False), dev(h, Ga, False), dev(h, Ca, False)
+        h.call("hipF_sgd_apply_segments", None, 6, ctypes.cast(segs, ctypes.c_void_p), first, count, dG.ptr, dW.ptr, dC.ptr)
+        gotW, gotC = dW.numpy()[0], dC.numpy()[0]
+        expW, expC = Wa.copy(), Ca.copy()
+        for (O_, I), (o, stride), (g, mom, lr, l2) in zip(layers, spans, hyper):
+            # the same step by hipF_affine_apply on copies of this layer (whole rows, padding included, as one matrix)
+            lw, lg, lc = (h.DevMatrix.from_numpy(a[o:o + O_ * stride].reshape(O_, stride).copy(), False) for a in (Wa, Ga, Ca))
+            lb, lgb, lcb = (dev(h, a[o + O_ * stride:o + O_ * stride + O_].copy(), False) for a in (Wa, Ga, Ca))
+            h.call("hipF_affine_apply", None, O_, stride, lg.ptr, stride, lgb.ptr, f32(g), f32(mom), f32(lr), f32(l2), lw.ptr, stride,
+                   lc.ptr, stride, lb.ptr, lcb.ptr)
+            expW[o:o + O_ * stride], expC[o:o + O_ * stride] = lw.numpy().ravel(), lc.numpy().ravel()
+            expW[o + O_ * stride:o + O_ * stride + O_], expC[o + O_ * stride:o + O_ * stride + O_] = lb.numpy()[0], lcb.numpy()[0]
+        inside = np.zeros(total, bool)
+        inside[first:first + count] = True
+        assert np.array_equal(gotW[inside], expW[inside]) and np.array_equal(gotW[~inside], Wa[~inside]), (first, count)
+        assert np.array_equal(gotC[inside], expC[inside]), (first, count)
+        assert np.array_equal(gotC[~inside], Ca[~inside])
+    with pytest.raises(h.HipError):
+        h.call("hipF_sgd_apply_segments", None, 6, ctypes.cast(segs, ctypes.c_void_p), 2, 8, dG.ptr, dW.ptr, dC.ptr)
+
+
 @pytest.mark.parametrize("N,O_,I", [(256, 1483, 1024), (256, 9000, 2048), (37, 50, 24), (64, 5000, 64), (64, 12000, 128)])
 def test_affine_forward_xent_equals_two_calls(hip, N, O_, I):
     """The fused output layer (GEMM + softmax + Xent::EvalVec) against hipF_affine_forward(softmax) followed by

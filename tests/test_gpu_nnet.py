@@ -292,8 +292,9 @@ def test_forward_tool_pipeline_ragged_utterances(hip, nn, tmp_path):
             assert np.array_equal(m, got_b[k])
         # Batching (several utterances per pass through the network, --batch-frames, default 4096): batches of
         # ~300 frames (utterances longer than a batch, many flushes) and one batch for everything give the bits
-        # of the default; one utterance at a time (0) may pick other GEMM plans and agrees to rounding.
-        for bf, exact in ((300, True), (1000000, True), (0, False)):
+        # of the default, and so does one utterance at a time (0): the tool always asks for products that sum a
+        # row's K range in one piece.
+        for bf, exact in ((300, True), (1000000, True), (0, True)):
             run_tool(nn, "nnet-forward", ["--silent=true", "--batch-frames=%d" % bf, str(tmp_path / "m.nnet"),
                                           "ark:" + str(tmp_path / "a.ark"), "ark:" + str(tmp_path / "oc.ark")])
             got_c = O.read_matrix_ark((tmp_path / "oc.ark").read_bytes())

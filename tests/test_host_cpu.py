@@ -27,23 +27,26 @@ def test_device_library_exports_every_declared_symbol():
 
 def test_public_header_is_plain_c_and_struct_layouts_match_the_binding(tmp_path):
     """include/kaldi_hip.h compiles as C (the boundary a foreign-function binding sees), and the structs that cross
-    it by value or by array -- MatrixDim, khAffineUpdate -- have the size and field offsets the ctypes mirror in
+    it by value or by array -- MatrixDim, khAffineUpdate, khAffineGradient, khSgdSegment -- have the size and field offsets the ctypes mirror in
     kaldi_amd/hip.py assumes."""
     import kaldi_amd.hip as h
-    fields = [f for f, _ in h.AffineUpdate._fields_]
     cname = {"in_": "in"}
+    structs = [("khAffineUpdate", h.AffineUpdate), ("khAffineGradient", h.AffineGradient), ("khSgdSegment", h.SgdSegment)]
+    lines = ['  printf("%zu\\n", sizeof(MatrixDim));\n']
+    for cn, py in structs:
+        lines.append('  printf("%%zu\\n", sizeof(%s));\n' % cn)
+        lines += ['  printf("%%zu\\n", offsetof(%s, %s));\n' % (cn, cname.get(f, f)) for f, _ in py._fields_]
     src = tmp_path / "layout.c"
-    src.write_text(
-        '#include <stddef.h>\n#include <stdio.h>\n#include "kaldi_hip.h"\nint main(void) {\n'
-        '  printf("%zu %zu\\n", sizeof(MatrixDim), sizeof(khAffineUpdate));\n' +
-        "".join('  printf("%%zu\\n", offsetof(khAffineUpdate, %s));\n' % cname.get(f, f) for f in fields) +
-        "  return 0;\n}\n")
+    src.write_text('#include <stddef.h>\n#include <stdio.h>\n#include "kaldi_hip.h"\nint main(void) {\n' + "".join(lines) +
+                   "  return 0;\n}\n")
     exe = tmp_path / "layout"
     subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
-    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()
-    assert int(out[0]) == ctypes.sizeof(h.MatrixDim) and int(out[1]) == ctypes.sizeof(h.AffineUpdate)
-    for f, off in zip(fields, out[2:]):
-        assert int(off) == getattr(h.AffineUpdate, f).offset, f
+    out = [int(x) for x in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
+    assert out.pop(0) == ctypes.sizeof(h.MatrixDim)
+    for cn, py in structs:
+        assert out.pop(0) == ctypes.sizeof(py), cn
+        for f, _ in py._fields_:
+            assert out.pop(0) == getattr(py, f).offset, (cn, f)
 
 
 def test_host_library_exports_capi():
