@@ -23,8 +23,12 @@
  *     path instantiates CuMatrix<double> (BaseFloat = float, base/kaldi-types.h:27).
  *   - arithmetic notes that matter for parity are written at each entry point.
  *   - threading: like the reference's cudamatrix layer (one host thread, a singleton device), the
- *     library is meant to be called from one host thread at a time; its state (default stream,
- *     per-stream workspaces, the pinned staging buffers of the blocking copies) is not locked.
+ *     library is meant to be driven by one host thread; its state (default stream, per-stream
+ *     workspaces, the pinned staging buffers of the blocking copies, the last error message) is not
+ *     locked.  The exceptions, callable from any thread beside that one: hipK_event_synchronize and
+ *     hipK_stream_synchronize on an event / a stream the caller owns -- they touch no library state on
+ *     success and are what a writer thread needs to wait for a copy queued by the driving thread
+ *     (nnet-forward's posterior writer does exactly and only that).
  */
 #ifndef KALDI_AMD_INCLUDE_KALDI_HIP_H_
 #define KALDI_AMD_INCLUDE_KALDI_HIP_H_

@@ -1,6 +1,11 @@
 // nnet-copy: reads a model and writes it back, possibly changing between the binary and the text
 // format (nnetbin/nnet-copy.cc:22-68).  The parameters pass through the device matrices of the
 // components, as in the reference.
+//
+// Command line, option names, usage text and log lines are derived from nnetbin/nnet-copy.cc of troylee/kaldi
+// (Copyright 2012 Karel Vesely), licensed under the Apache License, Version 2.0
+// (http://www.apache.org/licenses/LICENSE-2.0); this file is distributed under the same license, "AS IS",
+// without warranties or conditions of any kind.
 #include "base/kaldi-common.h"
 #include "nnet/nnet-nnet.h"
 #include "util/common-utils.h"

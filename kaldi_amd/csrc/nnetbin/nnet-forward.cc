@@ -8,6 +8,11 @@
 // utterance and queues its kernels, and the outputs travel to the host and into the table behind it
 // (PosteriorWriter).  Every utterance is still computed on its own, by the same kernels as before, so the
 // values written do not depend on what else is in flight.
+//
+// Command line, option names, usage text and log lines are derived from nnetbin/nnet-forward.cc of troylee/kaldi
+// (Copyright 2011 Karel Vesely), licensed under the Apache License, Version 2.0
+// (http://www.apache.org/licenses/LICENSE-2.0); this file is distributed under the same license, "AS IS",
+// without warranties or conditions of any kind.
 #include <limits>
 
 #include "base/kaldi-common.h"

@@ -4,6 +4,11 @@
 // (nnetbin/nnet-train-mse-tgtmat-frmshuff.cc:26-222); shares every kernel with the
 // cross-entropy trainer (Mse::Eval instead of Xent::EvalVec).  A feature / target pair with
 // different lengths is skipped (the reference never advanced past it).
+//
+// Command line, option names, usage text and log lines are derived from nnetbin/nnet-train-mse-tgtmat-frmshuff.cc of troylee/kaldi
+// (Copyright 2012 Karel Vesely), licensed under the Apache License, Version 2.0
+// (http://www.apache.org/licenses/LICENSE-2.0); this file is distributed under the same license, "AS IS",
+// without warranties or conditions of any kind.
 #include "base/kaldi-common.h"
 #include "cudamatrix/cu-device.h"
 #include "nnet/nnet-cache.h"

@@ -3,6 +3,11 @@
 // exit codes of the reference tool (nnetbin/nnet-train-xent-hardlab-frmshuff.cc:27-209); the
 // multi-GPU options (--num-ranks ...) are additions: synchronous data-parallel training, each
 // rank on its shard of the utterances, gradients summed with an RCCL all-reduce per layer.
+//
+// Command line, option names, usage text and log lines are derived from nnetbin/nnet-train-xent-hardlab-frmshuff.cc of troylee/kaldi
+// (Copyright 2011 Karel Vesely), licensed under the Apache License, Version 2.0
+// (http://www.apache.org/licenses/LICENSE-2.0); this file is distributed under the same license, "AS IS",
+// without warranties or conditions of any kind.
 #include "base/kaldi-common.h"
 #include "cudamatrix/cu-device.h"
 #include "nnet/nnet-cache.h"

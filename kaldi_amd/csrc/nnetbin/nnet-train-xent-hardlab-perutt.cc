@@ -3,6 +3,11 @@
 // tool (nnetbin/nnet-train-xent-hardlab-perutt.cc:26-170); it shares every kernel with the
 // frame-shuffled trainer.  An utterance whose alignment has the wrong length is skipped (the
 // reference never advanced past it).
+//
+// Command line, option names, usage text and log lines are derived from nnetbin/nnet-train-xent-hardlab-perutt.cc of troylee/kaldi
+// (Copyright 2011 Karel Vesely), licensed under the Apache License, Version 2.0
+// (http://www.apache.org/licenses/LICENSE-2.0); this file is distributed under the same license, "AS IS",
+// without warranties or conditions of any kind.
 #include "base/kaldi-common.h"
 #include "cudamatrix/cu-device.h"
 #include "nnet/nnet-loss.h"

@@ -1,6 +1,11 @@
 // rbm-convert-to-nnet: writes a trained RBM as <biasedlinearity> (+ <sigmoid> for Bernoulli hidden
 // units), the step between RBM pre-training of one layer and stacking the next
 // (nnetbin/rbm-convert-to-nnet.cc:22-75, Rbm::WriteAsNnet nnet/nnet-rbm.h:233-249).
+//
+// Command line, option names, usage text and log lines are derived from nnetbin/rbm-convert-to-nnet.cc of troylee/kaldi
+// (Copyright 2009-2011 Microsoft Corporation), licensed under the Apache License, Version 2.0
+// (http://www.apache.org/licenses/LICENSE-2.0); this file is distributed under the same license, "AS IS",
+// without warranties or conditions of any kind.
 #include "base/kaldi-common.h"
 #include "nnet/nnet-nnet.h"
 #include "nnet/nnet-rbm.h"

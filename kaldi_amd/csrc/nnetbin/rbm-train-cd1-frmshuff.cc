@@ -1,6 +1,11 @@
 // rbm-train-cd1-frmshuff: one epoch of contrastive-divergence (CD-1) training of a single RBM
 // on frame-shuffled minibatches.  Command line, defaults and log lines of the reference tool
 // (nnetbin/rbm-train-cd1-frmshuff.cc:29-191).
+//
+// Command line, option names, usage text and log lines are derived from nnetbin/rbm-train-cd1-frmshuff.cc of troylee/kaldi
+// (Copyright 2012 Karel Vesely), licensed under the Apache License, Version 2.0
+// (http://www.apache.org/licenses/LICENSE-2.0); this file is distributed under the same license, "AS IS",
+// without warranties or conditions of any kind.
 #include "base/kaldi-common.h"
 #include "cudamatrix/cu-device.h"
 #include "cudamatrix/cu-rand.h"

@@ -504,25 +504,37 @@ def test_recipe_scheduler_contract(hip, nn, tmp_path):
               O.BiasedLinearity((0.1 * rs.randn(dims[2], dims[1])).astype(f32), np.zeros(dims[2], f32)), O.Softmax(dims[2])]
     (tmp_path / "0.nnet").write_bytes(O.write_nnet(layers, True))
     exe = os.path.join(nn.BIN_DIR, "nnet-train-xent-hardlab-frmshuff")
+    # The option names of the script's two command lines and its awk program, as extracted from the script itself
+    # (tests/golden/make_scheduler_contract.py; tests/test_host_cpu.py re-derives them where the reference tree exists).
+    import json
+    contract = json.load(open(os.path.join(G, "scheduler_contract.json")))
+    # an identity transform, so that --feature-transform is passed too
+    ident = O.BiasedLinearity(np.eye(dims[0], dtype=f32), np.zeros(dims[0], f32))
+    (tmp_path / "ident.nnet").write_bytes(O.write_nnet([ident], True))
+    values = {"cross-validate": "true", "bunchsize": "64", "cachesize": "1024", "verbose": "1", "momentum": "0", "l1-penalty": "0",
+              "l2-penalty": "0", "randomize": "true", "binary": "true", "feature-transform": str(tmp_path / "ident.nnet"),
+              "learn-factors": "1.0,1.0", "average-grad": "false"}
+
+    def options(which, **extra):
+        vals = dict(values, **extra)
+        return ["--%s=%s" % (o, vals[o]) for o in contract[which]]
 
     def run(args, log):
         with open(log, "ab") as lf:
             assert subprocess.run([exe] + args, stderr=lf, stdout=subprocess.DEVNULL, timeout=100).returncode == 0
-        out = subprocess.run(["awk", '/FRAME_ACCURACY/{ acc=$3; sub(/%/,"",acc); } END{print acc}', log],
-                             stdout=subprocess.PIPE).stdout.decode().strip()
+        out = subprocess.run(["awk", contract["awk_program"], log], stdout=subprocess.PIPE).stdout.decode().strip()
         return float(out)
 
-    common = ["--bunchsize=64", "--cachesize=1024", "--verbose=1"]
     best, lr = str(tmp_path / "0.nnet"), 0.5
-    acc = run(["--cross-validate=true"] + common + ["ark:" + str(tmp_path / "cv.ark"), "ark:" + str(tmp_path / "cv.ali"), best],
+    acc = run(options("prerun_options") + ["ark:" + str(tmp_path / "cv.ark"), "ark:" + str(tmp_path / "cv.ali"), best],
               str(tmp_path / "iter00.initial.log"))
     first, accepted = acc, 0
     for it in range(1, 6):
         nxt = str(tmp_path / ("iter%02d.nnet" % it))
-        run(["--learn-rate=%g" % lr, "--momentum=0", "--l1-penalty=0", "--l2-penalty=0"] + common +
-            ["--randomize=true", "--binary=true", "ark:" + str(tmp_path / "tr.ark"), "ark:" + str(tmp_path / "tr.ali"), best, nxt],
+        run(options("train_options", **{"learn-rate": "%g" % lr}) +
+            ["ark:" + str(tmp_path / "tr.ark"), "ark:" + str(tmp_path / "tr.ali"), best, nxt],
             str(tmp_path / ("iter%02d.tr.log" % it)))
-        acc_new = run(["--cross-validate=true"] + common + ["ark:" + str(tmp_path / "cv.ark"), "ark:" + str(tmp_path / "cv.ali"), nxt],
+        acc_new = run(options("crossval_options") + ["ark:" + str(tmp_path / "cv.ark"), "ark:" + str(tmp_path / "cv.ali"), nxt],
                       str(tmp_path / ("iter%02d.cv.log" % it)))
         prev = acc
         if acc_new > acc:

@@ -115,3 +115,23 @@ def test_reference_sources_compile_against_these_headers(tmp_path):
             if r.returncode != 0:
                 failures.append("%s: %s" % (f, r.stderr.decode()[:1500]))
     assert not failures, "\n".join(failures)
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/egs"), reason="the reference tree is only present in the build container")
+def test_scheduler_contract_fixture_matches_the_reference_script():
+    """tests/golden/scheduler_contract.json -- the option names and the awk program that
+    tests/test_gpu_nnet.py::test_recipe_scheduler_contract drives the trainer with -- is what
+    egs/aurora4/a00/steps/nnet_scheduler/train_scheduler.sh:76-120 of the reference holds."""
+    import importlib.util
+    import json
+    spec = importlib.util.spec_from_file_location("make_scheduler_contract", os.path.join(ROOT, "tests", "golden", "make_scheduler_contract.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    want = mod.extract("/root/reference")
+    got = json.load(open(os.path.join(ROOT, "tests", "golden", "scheduler_contract.json")))
+    assert got == want
+    # every option the script passes is one the trainer registers
+    exe = os.path.join(ROOT, "kaldi_amd", "bin", "nnet-train-xent-hardlab-frmshuff")
+    usage = subprocess.run([exe, "--help"], stdout=subprocess.PIPE, stderr=subprocess.PIPE).stderr.decode()
+    for o in set(got["train_options"]) | set(got["crossval_options"]):
+        assert ("--" + o) in usage, o
