@@ -9,6 +9,14 @@
 
 namespace kaldi {
 
+/// dst <- src where dst already has src's shape (Component::Propagate / Backpropagate have sized it).  Written in
+/// place also when dst is a window onto memory owned elsewhere -- the last component of a forward pass writes
+/// straight into the caller's output slot -- where CopyFromMat would let go of the window and allocate.
+inline void CopyInPlace(const CuMatrix<BaseFloat> &src, CuMatrix<BaseFloat> *dst) {
+  KALDI_ASSERT(dst->NumRows() == src.NumRows() && dst->NumCols() == src.NumCols());
+  dst->CopyFromMat(src, 0, src.NumRows(), 0, src.NumCols());
+}
+
 /// y = s*x
 class Scale : public Component {
  public:
@@ -21,11 +29,11 @@ class Scale : public Component {
     if (!binary) os << "\n";
   }
   void PropagateFnc(const CuMatrix<BaseFloat> &in, CuMatrix<BaseFloat> *out) {
-    out->CopyFromMat(in);
+    CopyInPlace(in, out);
     out->Scale(scale_);
   }
   void BackpropagateFnc(const CuMatrix<BaseFloat> &in_err, CuMatrix<BaseFloat> *out_err) {
-    out_err->CopyFromMat(in_err);
+    CopyInPlace(in_err, out_err);
     out_err->Scale(scale_);
   }
 
@@ -60,11 +68,11 @@ class Dropout : public Component {
       prob_.Set(1 - drop_ratio_);
     }
     cu_rand_.BinarizeProbs(prob_, &mask_);
-    out->CopyFromMat(in);
+    CopyInPlace(in, out);
     out->MulElements(mask_);
   }
   void BackpropagateFnc(const CuMatrix<BaseFloat> &in_err, CuMatrix<BaseFloat> *out_err) {
-    out_err->CopyFromMat(in_err);
+    CopyInPlace(in_err, out_err);
     out_err->MulElements(mask_);
   }
 
@@ -90,7 +98,7 @@ class Softmax : public Component {
   void PropagateFnc(const CuMatrix<BaseFloat> &in, CuMatrix<BaseFloat> *out) { cu::Softmax(in, out); }
   /// The error is passed through: with the cross-entropy objective the incoming error
   /// (posterior - target) already is the derivative w.r.t. the softmax input.
-  void BackpropagateFnc(const CuMatrix<BaseFloat> &in_err, CuMatrix<BaseFloat> *out_err) { out_err->CopyFromMat(in_err); }
+  void BackpropagateFnc(const CuMatrix<BaseFloat> &in_err, CuMatrix<BaseFloat> *out_err) { CopyInPlace(in_err, out_err); }
 };
 
 class Relu : public Component {

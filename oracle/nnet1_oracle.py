@@ -274,6 +274,86 @@ class Copy:
         return copy_cols(x, self.indices)
 
 
+class Relu:
+    """nnet/nnet-activation.h:123-147 over cu::Relu / cu::DiffRelu, CPU branch (cudamatrix/cu-math-inl.h:39-90):
+    y = x > 0 ? x : 0 ; eout = ein * (y > 0), y = this layer's output.  (The reference's GPU wrappers send
+    cuda_diff_relu to the diff_sigmoid kernel, cu-kernels.h:143-145; the kernels themselves, cu-kernels.cu:526-545,
+    compute what the CPU branch does, and that is what is restated here.)"""
+    marker = "<relu>"
+    updatable = False
+
+    def __init__(self, dim):
+        self.dim_in = self.dim_out = dim
+
+    def propagate(self, x):
+        x = np.asarray(x, f32)
+        return np.where(x > 0, x, f32(0)).astype(f32)
+
+    def backpropagate(self, err, y_in=None, y_out=None):
+        return (np.asarray(err, f32) * (np.asarray(y_out, f32) > 0)).astype(f32)
+
+
+class SoftRelu:
+    """nnet/nnet-activation.h:149-174 over cu::SoftRelu / cu::DiffSoftRelu, CPU branch (cu-math-inl.h:92-147):
+    y = x > 4 ? x : log(1 + exp(x)) ; eout = x > 4 ? ein : ein * e^x / (1 + e^x), x = this layer's INPUT.  The
+    C++ expressions mix float operands with double literals: computed in double, rounded on assignment."""
+    marker = "<softrelu>"
+    updatable = False
+
+    def __init__(self, dim):
+        self.dim_in = self.dim_out = dim
+
+    def propagate(self, x):
+        x = np.asarray(x, f32)
+        soft = np.log(1.0 + np.exp(x.astype(np.float32)).astype(np.float64))   # exp(float) -> float, 1 + . in double, log in double
+        return np.where(x > 4.0, x, soft.astype(f32)).astype(f32)
+
+    def backpropagate(self, err, y_in=None, y_out=None):
+        x, e = np.asarray(y_in, f32), np.asarray(err, f32)
+        f = np.exp(x)                                                            # Real f = exp(x)
+        soft = (e * f).astype(f32).astype(np.float64) / (1.0 + f.astype(np.float64))   # ein * f / (1.0 + f)
+        return np.where(x > 4.0, e, soft.astype(f32)).astype(f32)
+
+
+class Scale:
+    """nnet/nnet-activation.h:27-70: y = s * x both ways; one float of data.  (The marker carries the reference's
+    typo, nnet-component.cc:44.)"""
+    marker = ",<scale>"
+    updatable = False
+
+    def __init__(self, dim, scale=1.0):
+        self.dim_in = self.dim_out = dim
+        self.scale = f32(scale)
+
+    def propagate(self, x):
+        return (np.asarray(x, f32) * self.scale).astype(f32)
+
+    def backpropagate(self, err, y_in=None, y_out=None):
+        return (np.asarray(err, f32) * self.scale).astype(f32)
+
+
+class Dropout:
+    """nnet/nnet-activation.h:72-121: y = mask .* x, the same mask for the error; mask = (1 - ratio > uniform).
+    The draws are injected (`uniform`): the reference's CPU branch of CuRand::BinarizeProbs never sizes its state
+    (cu-rand-inl.h:162-168) and cannot run this component, so nothing pins the stream itself."""
+    marker = "<dropout>"
+    updatable = False
+
+    def __init__(self, dim, ratio=0.5):
+        self.dim_in = self.dim_out = dim
+        self.ratio = f32(ratio)
+        self.mask = None
+        self.uniform = None
+
+    def propagate(self, x):
+        x = np.asarray(x, f32)
+        self.mask = binarize_probs(np.full(x.shape, f32(1) - self.ratio, f32), self.uniform)
+        return (x * self.mask).astype(f32)
+
+    def backpropagate(self, err, y_in=None, y_out=None):
+        return (np.asarray(err, f32) * self.mask).astype(f32)
+
+
 class Nnet:
     """nnet/nnet-nnet.{h,cc}."""
 
@@ -685,6 +765,10 @@ def write_nnet(layers, binary):
             out += write_vector(np.asarray(l.offsets, np.float64), binary, double=True)
         elif isinstance(l, Copy):
             out += write_vector(np.asarray(l.indices, np.float64) + 1.0, binary, double=True)
+        elif isinstance(l, (Scale, Dropout)):
+            v = l.scale if isinstance(l, Scale) else l.ratio
+            # WriteBasicType<float> (io-funcs-inl.h:30-48): binary = size byte + 4 bytes, text = value + space
+            out += (b"\x04" + np.float32(v).tobytes()) if binary else (_cxx_float(v) + " \n").encode()
     return out
 
 
@@ -716,6 +800,15 @@ class _Reader:
             self.p += 5
             return v
         return int(self.token(False))
+
+    def f32(self, binary):
+        """ReadBasicType<float> (io-funcs.cc)"""
+        if binary:
+            assert self.d[self.p] == 4, "expected float size byte"
+            v = struct.unpack_from("<f", self.d, self.p + 1)[0]
+            self.p += 5
+            return v
+        return float(self.token(False))
 
     def matrix(self, binary):
         if binary:
@@ -811,6 +904,13 @@ def read_nnet(data):
             layers.append(Expand(dim_in, dim_out, rd.vector(binary)))
         elif marker == "<copy>":
             layers.append(Copy(dim_in, dim_out, rd.vector(binary) - 1.0))
+        elif marker == "<relu>":
+            layers.append(Relu(dim_out))
+        elif marker == "<softrelu>":
+            layers.append(SoftRelu(dim_out))
+        elif marker in (",<scale>", "<dropout>"):
+            v = rd.f32(binary)
+            layers.append(Scale(dim_out, v) if marker == ",<scale>" else Dropout(dim_out, v))
         else:
             raise ValueError("Unknown marker" + marker)
     return layers

@@ -398,6 +398,48 @@ def gen_transform(tmp):
     print("transform_small: %d arrays" % len(fix))
 
 
+def gen_activations(tmp):
+    """The components the factory builds beside <sigmoid> / <softmax> (nnet/nnet-activation.h:27-174) through the
+    reference's own tools on its CPU path: a 24 -> 32 <relu> -> 32 <softrelu> -> ,<scale> 0.5 -> 17 <softmax> network
+    in nnet-forward (posteriors, and the text / binary model as nnet-copy re-writes it) and one epoch of
+    nnet-train-xent-hardlab-frmshuff (report and trained model).  Four units of the second layer get a bias of 4.5,
+    so both branches of <softrelu> (x > 4) run.  <dropout> cannot run on the reference's CPU path (its random
+    generator's CPU branch never sizes its state) and has no fixture."""
+    rs = np.random.RandomState(4242)
+    dims = [24, 32, 32, 17]
+    W = [(0.1 * rs.randn(dims[i + 1], dims[i])).astype(f32) for i in range(3)]
+    b = [(-0.5 + 0.2 * rs.rand(dims[1])).astype(f32), (-0.5 + 0.2 * rs.rand(dims[2])).astype(f32), np.zeros(dims[3], f32)]
+    b[1][:4] = 4.5
+    layers = [O.BiasedLinearity(W[0], b[0]), O.Relu(dims[1]), O.BiasedLinearity(W[1], b[1]), O.SoftRelu(dims[2]),
+              O.Scale(dims[2], 0.5), O.BiasedLinearity(W[2], b[2]), O.Softmax(dims[3])]
+    lengths = [30, 5, 40, 17, 1, 38, 33, 21, 29]
+    utts = [("spk%02d" % i, rs.randn(n, dims[0]).astype(f32)) for i, n in enumerate(lengths)]
+    alis = [(k, rs.randint(0, dims[-1], m.shape[0]).astype(np.int32)) for k, m in utts]
+    model = O.write_nnet(layers, True)
+    P = lambda n: os.path.join(tmp, n)
+    open(P("am.bin"), "wb").write(model)
+    open(P("af.ark"), "wb").write(O.write_matrix_ark(utts))
+    open(P("aa.ark"), "wb").write(O.write_int32_vector_ark(alis, binary=False))
+    fix = {"model": np.frombuffer(model, np.uint8), "feats_ark": np.frombuffer(O.write_matrix_ark(utts), np.uint8),
+           "ali_ark_txt": np.frombuffer(O.write_int32_vector_ark(alis, binary=False), np.uint8)}
+    run([os.path.join(BIN, "nnet-copy"), "--binary=false", P("am.bin"), P("am.txt")])
+    run([os.path.join(BIN, "nnet-copy"), "--binary=true", P("am.txt"), P("am2.bin")])
+    fix["model_txt"] = np.frombuffer(open(P("am.txt"), "rb").read(), np.uint8)
+    fix["model_bin_rewritten"] = np.frombuffer(open(P("am2.bin"), "rb").read(), np.uint8)
+    run([os.path.join(BIN, "nnet-forward"), P("am.bin"), "ark:" + P("af.ark"), "ark:" + P("ao.ark")])
+    fix["forward_ark"] = np.frombuffer(open(P("ao.ark"), "rb").read(), np.uint8)
+    for name, opts in {"plain": ["--randomize=false"], "mom": ["--randomize=false", "--momentum=0.9", "--learn-rate=0.05", "--average-grad=true"]}.items():
+        _, err = run([os.path.join(BIN, "nnet-train-xent-hardlab-frmshuff"), "--bunchsize=16", "--cachesize=64", "--binary=true"] + opts +
+                     ["ark:" + P("af.ark"), "ark:" + P("aa.ark"), P("am.bin"), P("aout.nnet")])
+        m = re.search(r"Xent:(\S+) frames:(\d+) err/frm:(\S+)\s*\nFRAME_ACCURACY >> (\S+)% <<", err)
+        fix["%s_xent" % name] = np.float64(m.group(1))
+        fix["%s_frames" % name] = np.int64(m.group(2))
+        fix["%s_report" % name] = np.frombuffer(m.group(0).encode(), np.uint8)
+        fix["%s_model_out" % name] = np.frombuffer(open(P("aout.nnet"), "rb").read(), np.uint8)
+    np.savez_compressed(os.path.join(HERE, "activations_small.npz"), **fix)
+    print("activations_small: %d arrays" % len(fix))
+
+
 def rm_shape_net(seed):
     """the RM-sized model, bunch and labels of gen_rm_shape / gen_rm_multistep, regenerated from the seed by the tests"""
     rs = np.random.RandomState(seed)
@@ -448,7 +490,7 @@ def gen_rm_multistep(tmp):
 
 
 GENERATORS = {"rm_multistep": gen_rm_multistep, "dnn_steps": gen_dnn_steps, "forward": gen_forward, "train_e2e": gen_train_e2e, "rbm": gen_rbm,
-              "rm_shape": gen_rm_shape, "siblings": gen_siblings, "transform": gen_transform}
+              "rm_shape": gen_rm_shape, "siblings": gen_siblings, "transform": gen_transform, "activations": gen_activations}
 
 if __name__ == "__main__":
     if not os.path.exists(os.path.join(BIN, "ref_dump")):

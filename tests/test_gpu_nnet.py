@@ -722,3 +722,85 @@ def test_cache_and_host_io_errors(hip, nn, tmp_path):
         nn.Trainer(str(tmp_path / "junk.nnet"))
     with pytest.raises(nn.NnetError):
         nn.Trainer(str(tmp_path / "does_not_exist"))
+
+
+@pytest.mark.parametrize("fused", ["true", "false"])
+def test_relu_softrelu_scale_in_the_tools_match_reference(hip, nn, tmp_path, fused):
+    """The activation components beside <sigmoid> / <softmax> (nnet/nnet-activation.h:27-174 of the reference), built by
+    the component factory and run through Nnet::Feedforward / Propagate / Backpropagate in the tools, against what the
+    reference's tools produced for the same 24 -> 32 <relu> -> 32 <softrelu> -> ,<scale> 0.5 -> 17 <softmax> model
+    (tests/golden/make_golden.py: activations): model bytes through nnet-copy, posteriors, one training epoch with and
+    without momentum.  The kernels compute the reference's kernel / CPU formulas (cu-kernels.cu:526-572,
+    cu-math-inl.h:39-147), not what its GPU wrappers dispatch to by mistake (cu-kernels.h:143-145 sends diff_relu,
+    softrelu and diff_softrelu to other kernels)."""
+    g = load("activations_small.npz")
+    P = lambda n: str(tmp_path / n)
+    for n, key in (("m.bin", "model"), ("f.ark", "feats_ark"), ("a.ark", "ali_ark_txt")):
+        (tmp_path / n).write_bytes(g[key].tobytes())
+    run_tool(nn, "nnet-copy", ["--binary=false", P("m.bin"), P("m.txt")])
+    run_tool(nn, "nnet-copy", ["--binary=true", P("m.txt"), P("m2.bin")])
+    assert (tmp_path / "m.txt").read_bytes() == g["model_txt"].tobytes()
+    assert (tmp_path / "m2.bin").read_bytes() == g["model_bin_rewritten"].tobytes()
+    run_tool(nn, "nnet-forward", ["--fused=" + fused, P("m.txt"), "ark:" + P("f.ark"), "ark:" + P("o.ark")])
+    ref = O.read_matrix_ark(g["forward_ark"].tobytes())
+    got = O.read_matrix_ark((tmp_path / "o.ark").read_bytes())
+    assert [k for k, _ in got] == [k for k, _ in ref]
+    for (_, a), (_, b) in zip(got, ref):
+        np.testing.assert_allclose(a, b, rtol=1e-4, atol=1e-7)
+    for name, opts in (("plain", []), ("mom", ["--momentum=0.9", "--learn-rate=0.05", "--average-grad=true"])):
+        _, err = run_tool(nn, "nnet-train-xent-hardlab-frmshuff",
+                          ["--bunchsize=16", "--cachesize=64", "--binary=true", "--randomize=false", "--fused=" + fused] + opts +
+                          ["ark:" + P("f.ark"), "ark:" + P("a.ark"), P("m.bin"), P("out.nnet")])
+        m = re.search(r"Xent:(\S+) frames:(\d+) err/frm:(\S+)\s*\nFRAME_ACCURACY >> (\S+)% <<", err)
+        assert m, err
+        assert int(m.group(2)) == int(g[name + "_frames"])
+        assert m.group(4) == re.search(r">> (\S+)% <<", g[name + "_report"].tobytes().decode()).group(1)
+        assert abs(float(m.group(1)) - float(g[name + "_xent"])) <= 1e-3 * float(g[name + "_xent"])
+        _model_close(tmp_path / "out.nnet", g[name + "_model_out"].tobytes())
+
+
+def test_dropout_component_mask_statistics_and_backprop_parity_unpinned(hip, nn, tmp_path):
+    """<dropout> (nnet/nnet-activation.h:72-121 of the reference): y = mask .* x with mask ~ Bernoulli(1 - ratio), and the
+    SAME mask on the error in Backpropagate.  Parity unpinned: the reference's CPU path cannot run the component (its
+    generator's CPU branch never sizes its state, cu-rand-inl.h:162-168) and no CUDA build exists here, so there is
+    no reference output; what is checked is the definition itself.
+      forward: nnet-forward on a model that is one <dropout>, input all ones -> the output IS the mask: zeros and ones
+        only, a fraction 1 - ratio of ones, another mask for every utterance;
+      training: <biasedlinearity> <dropout> <biasedlinearity> <softmax>, one frame per step.  With one frame the update
+        of the upper layer leaves exactly the columns of dropped units unchanged (forward mask) and the update of the
+        lower layer exactly the rows of units whose error was dropped (backward mask): the two sets must be equal."""
+    D, C, ratio = 1024, 16, 0.3
+    rs = np.random.RandomState(8)
+    drop = O.Dropout(D, ratio)
+    (tmp_path / "d.nnet").write_bytes(O.write_nnet([drop], True))
+    utts = [("u%d" % i, np.ones((n, D), f32)) for i, n in enumerate((200, 200, 57))]
+    (tmp_path / "f.ark").write_bytes(O.write_matrix_ark(utts))
+    run_tool(nn, "nnet-forward", [str(tmp_path / "d.nnet"), "ark:" + str(tmp_path / "f.ark"), "ark:" + str(tmp_path / "o.ark")])
+    masks = [m for _, m in O.read_matrix_ark((tmp_path / "o.ark").read_bytes())]
+    for m in masks:
+        assert set(np.unique(m).tolist()) <= {0.0, 1.0}
+        assert abs(m.mean() - (1 - ratio)) < 0.01
+        sd = np.sqrt(ratio * (1 - ratio))
+        assert np.abs(m.mean(axis=0) - (1 - ratio)).max() < 5.5 * sd / np.sqrt(m.shape[0])   # no stuck unit,
+        assert np.abs(m.mean(axis=1) - (1 - ratio)).max() < 5.5 * sd / np.sqrt(m.shape[1])   # no stuck frame
+    assert not np.array_equal(masks[0], masks[1])
+    # one frame, one step: forward and backward masks from the two updates
+    I = 64
+    W1, b1 = (0.3 * rs.randn(D, I)).astype(f32), (0.1 * rs.randn(D)).astype(f32)
+    W2, b2 = (0.3 * rs.randn(C, D)).astype(f32), np.zeros(C, f32)
+    layers = [O.BiasedLinearity(W1, b1), O.Dropout(D, ratio), O.BiasedLinearity(W2, b2), O.Softmax(C)]
+    (tmp_path / "t.nnet").write_bytes(O.write_nnet(layers, True))
+    for fused in (True, False):
+        tr = nn.Trainer(str(tmp_path / "t.nnet"))
+        tr.set_train_opts(0.5, 0.0, 0.0, 0.0, 0.0, False, fused)
+        x = hip.DevMatrix.from_numpy(rs.randn(1, I).astype(f32))
+        t = hip.DevMatrix.from_numpy(np.array([3], np.int32), pitched=False)
+        tr.train_bunch(x.ptr, x.stride, 1, I, t.ptr)
+        nW1, nb1 = tr.layer_params(0, D, I)
+        nW2, _ = tr.layer_params(2, C, D)
+        tr.close()
+        fwd_kept = np.any(nW2 != W2, axis=0)       # column j of the upper layer moved <=> unit j was kept in the forward pass
+        bwd_kept = nb1 != b1                       # bias j of the lower layer moved <=> the error of unit j was kept
+        assert np.array_equal(fwd_kept, bwd_kept), fused
+        assert abs(fwd_kept.mean() - (1 - ratio)) < 0.06
+        assert np.array_equal(np.any(nW1 != W1, axis=1), bwd_kept)

@@ -402,3 +402,30 @@ def test_rm_shape_multistep_matches_reference(name, mom):
               rtol=1e-4, atol=1e-6)
         assert abs(np.abs(W.astype(np.float64)).sum() - float(g["%s_W%d_abs_sum" % (name, i)])) < 1e-4 * float(g["%s_W%d_abs_sum" % (name, i)])
         close(net.layers[i].b, g["%s_b%d" % (name, i)], rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("name,opts", [("plain", dict(learn_rate=0.008)),
+                                       ("mom", dict(learn_rate=0.05, momentum=0.9, average_grad=True))])
+def test_relu_softrelu_scale_match_reference(name, opts):
+    """The oracle's <relu>, <softrelu> and ,<scale> (nnet/nnet-activation.h:27-174) against the reference's tools on a
+    24 -> 32 relu -> 32 softrelu -> scale 0.5 -> 17 softmax network: model bytes in both formats, nnet-forward
+    posteriors, and one epoch of the trainer (report, trained weights)."""
+    g = load("activations_small.npz")
+    layers = O.read_nnet(g["model"].tobytes())
+    assert [l.marker for l in layers] == ["<biasedlinearity>", "<relu>", "<biasedlinearity>", "<softrelu>", ",<scale>",
+                                          "<biasedlinearity>", "<softmax>"]
+    assert O.write_nnet(layers, False) == g["model_txt"].tobytes()
+    assert O.write_nnet(O.read_nnet(g["model_txt"].tobytes()), True) == g["model_bin_rewritten"].tobytes()
+    net = O.Nnet(layers)
+    feats = dict(O.read_matrix_ark(g["feats_ark"].tobytes()))
+    some_above_4 = False
+    for k, ref in O.read_matrix_ark(g["forward_ark"].tobytes()):
+        close(net.feedforward(feats[k]), ref, rtol=2e-5, atol=1e-7)
+        net.propagate(feats[k])
+        some_above_4 |= bool((net.propagate_buf[3] > 4.0).any()) and bool((net.propagate_buf[3] <= 4.0).any())
+    assert some_above_4                                        # both branches of <softrelu> ran
+    net, xent, _ = run_trainer(g, opts, False)
+    assert xent.frames == int(g[name + "_frames"])
+    assert abs(xent.loss - float(g[name + "_xent"])) <= 2e-5 * abs(xent.loss)
+    assert xent.report().split("\n")[1] == g[name + "_report"].tobytes().decode().split("\n")[1]
+    _check_models(net, g[name + "_model_out"].tobytes())
