@@ -32,6 +32,20 @@ int static_scratch_setup(int device) {
 
 namespace {
 
+// 16-byte buffer accesses to a row of floats: the descriptor ends with the row's last whole group of 4 columns, so
+// lanes past the end read 0 and write nothing, without a branch around the access.
+typedef int kh_v4i __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t row_rsrc(const float *p, int cols) {
+  return __builtin_amdgcn_make_buffer_rsrc((void *)p, 0, ((cols + 3) & ~3) * 4, 0x00020000);
+}
+__device__ __forceinline__ float4 row_load4(__amdgpu_buffer_rsrc_t rs, int c) {
+  const kh_v4i r = __builtin_amdgcn_raw_buffer_load_b128(rs, c * 4, 0, 0);
+  return make_float4(__int_as_float(r.x), __int_as_float(r.y), __int_as_float(r.z), __int_as_float(r.w));
+}
+__device__ __forceinline__ void row_store4(__amdgpu_buffer_rsrc_t rs, int c, float a, float b, float cc, float d) {
+  kh_v4i v = {__float_as_int(a), __float_as_int(b), __float_as_int(cc), __float_as_int(d)};
+  __builtin_amdgcn_raw_buffer_store_b128(v, rs, c * 4, 0, 0);
+}
 // ---- vec[c] = alpha * sum_r mat[r,c] + beta * vec[c] ---------------------------------------
 // Block = 64 columns x 16 row groups; lane -> column keeps every wave load a contiguous 256 B.
 // The per-group partial sums are combined in a fixed order, so results are reproducible.
@@ -62,6 +76,90 @@ __global__ __launch_bounds__(1024) void col_sums_kernel(float alpha, const float
   }
 }
 
+// Tall matrices (a whole frame cache): the same sums in two stages, so that every compute unit reads.  Stage 1: the
+// rows are cut into `nslab` slabs; a 256-thread workgroup sums one slab of up to 2048 columns, its 4 waves taking
+// rows in turn, combined in wave order through LDS into part[slab][col].  Stage 2 is the single-stage kernel above on
+// the matrix of partial sums.  The order of the additions is fixed by the shape alone: same bits every run.
+template <int NV>
+__global__ __launch_bounds__(1024) void col_sums_slab_kernel(const float *mat, MatrixDim d, int rows_per_slab, float *part,
+                                                             int ldpart) {
+  // this workgroup: rows [r0, r1) x columns [c0, c0 + 256 * NV); a lane owns 4 adjacent columns in each of NV groups
+  // of 256, so a wave instruction reads 1 KB of one row and each of the 16 waves walks along whole rows (two in
+  // flight); the waves' sums are combined four at a time through LDS, in wave order
+  __shared__ float red[4][256 * NV];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int c0 = blockIdx.x * 256 * NV;
+  const int r0 = blockIdx.y * rows_per_slab, r1 = min(d.rows, r0 + rows_per_slab);
+  const int ncols = min(d.cols - c0, 256 * NV);
+  float4 acc[NV];
+#pragma unroll
+  for (int k = 0; k < NV; ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+  int r = r0 + w;
+  for (; r + 16 < r1; r += 32) {
+    const __amdgpu_buffer_rsrc_t ra = row_rsrc(mat + (size_t)r * d.stride + c0, ncols);
+    const __amdgpu_buffer_rsrc_t rb = row_rsrc(mat + (size_t)(r + 16) * d.stride + c0, ncols);
+    float4 xa[NV], xb[NV];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) xa[k] = row_load4(ra, (lane + k * 64) * 4);
+#pragma unroll
+    for (int k = 0; k < NV; ++k) xb[k] = row_load4(rb, (lane + k * 64) * 4);
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      acc[k].x += xa[k].x; acc[k].y += xa[k].y; acc[k].z += xa[k].z; acc[k].w += xa[k].w;
+    }
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      acc[k].x += xb[k].x; acc[k].y += xb[k].y; acc[k].z += xb[k].z; acc[k].w += xb[k].w;
+    }
+  }
+  for (; r < r1; r += 16) {
+    const __amdgpu_buffer_rsrc_t ra = row_rsrc(mat + (size_t)r * d.stride + c0, ncols);
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const float4 x = row_load4(ra, (lane + k * 64) * 4);
+      acc[k].x += x.x; acc[k].y += x.y; acc[k].z += x.z; acc[k].w += x.w;
+    }
+  }
+  float tot[NV];  // thread t (< 256) ends up with columns t, t + 256, ...
+#pragma unroll
+  for (int k = 0; k < NV; ++k) tot[k] = 0.f;
+  for (int round = 0; round < 4; ++round) {
+    __syncthreads();
+    if ((w >> 2) == round) {
+#pragma unroll
+      for (int k = 0; k < NV; ++k) *reinterpret_cast<float4 *>(&red[w & 3][(lane + k * 64) * 4]) = acc[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < 256) {
+#pragma unroll
+      for (int k = 0; k < NV; ++k) {
+        const int i = threadIdx.x + k * 256;
+        tot[k] += (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
+      }
+    }
+  }
+  if (threadIdx.x < 256) {
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const int i = threadIdx.x + k * 256;
+      if (i < ncols) part[(size_t)blockIdx.y * ldpart + c0 + i] = tot[k];
+    }
+  }
+}
+// any layout (rows not 16-byte aligned): a lane owns one column of 64
+__global__ __launch_bounds__(256) void col_sums_slab_scalar_kernel(const float *mat, MatrixDim d, int rows_per_slab, float *part,
+                                                                   int ldpart) {
+  __shared__ float red[4][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
+  const int r0 = blockIdx.y * rows_per_slab, r1 = min(d.rows, r0 + rows_per_slab);
+  float acc = 0.f;
+  if (c < d.cols)
+    for (int r = r0 + w; r < r1; r += 4) acc += mat[(size_t)r * d.stride + c];
+  red[w][lane] = acc;
+  __syncthreads();
+  if (w == 0 && c < d.cols) part[(size_t)blockIdx.y * ldpart + c] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+}
 // ---- vec[r] = alpha * sum_c mat[r,c] + beta * vec[r] ---------------------------------------
 __global__ __launch_bounds__(256) void row_sums_kernel(float alpha, const float *mat, MatrixDim d, float beta,
                                                        float *vec) {
@@ -134,18 +232,6 @@ __global__ __launch_bounds__(kSoftmaxThreads) void softmax_kernel(float *y, int 
 // and the loads of a phase -- every slab and the bias -- are all in flight together.  (With a branch per
 // access, every guarded load became a memory round trip of its own.)  Columns of the last group that lie past
 // `cols` hold padding: they are masked out of max and sum and stored as 0.
-typedef int kh_v4i __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t row_rsrc(const float *p, int cols) {
-  return __builtin_amdgcn_make_buffer_rsrc((void *)p, 0, ((cols + 3) & ~3) * 4, 0x00020000);
-}
-__device__ __forceinline__ float4 row_load4(__amdgpu_buffer_rsrc_t rs, int c) {
-  const kh_v4i r = __builtin_amdgcn_raw_buffer_load_b128(rs, c * 4, 0, 0);
-  return make_float4(__int_as_float(r.x), __int_as_float(r.y), __int_as_float(r.z), __int_as_float(r.w));
-}
-__device__ __forceinline__ void row_store4(__amdgpu_buffer_rsrc_t rs, int c, float a, float b, float cc, float d) {
-  kh_v4i v = {__float_as_int(a), __float_as_int(b), __float_as_int(cc), __float_as_int(d)};
-  __builtin_amdgcn_raw_buffer_store_b128(v, rs, c * 4, 0, 0);
-}
 template <int NV>
 __device__ __forceinline__ float softmax_row_regs(float4 (&v)[NV], const float *px, int nslab, size_t slab_stride,
                                                   const float *bias, int cols, float *red) {
@@ -224,6 +310,45 @@ __global__ __launch_bounds__(kSoftmaxThreads) void softmax_vec_kernel(float *y, 
     row_store4(rsy, (threadIdx.x + k * kSoftmaxThreads) * 4, v[k].x * inv, v[k].y * inv, v[k].z * inv, v[k].w * inv);
 }
 
+// Short rows (cols <= 256 * NV), a matrix of many of them: one WAVE per row, four rows per workgroup.  The row lives
+// in NV float4 per lane (16-byte buffer loads bounded by the row's descriptor, all in flight together), maximum and
+// sum are wave reductions: no LDS, no barrier, a quarter of the workgroups.  Plain softmax only (one slab, no bias).
+template <int NV>
+__global__ __launch_bounds__(256) void softmax_wave_kernel(float *y, int ldy, const float *x, int ldx, int rows, int cols) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  const __amdgpu_buffer_rsrc_t rs = row_rsrc(x + (size_t)r * ldx, cols);
+  float4 v[NV];
+#pragma unroll
+  for (int k = 0; k < NV; ++k) v[k] = row_load4(rs, (lane + k * 64) * 4);
+  float mx = -INFINITY;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const int c = (lane + k * 64) * 4;
+    mx = fmaxf(mx, (c < cols) ? v[k].x : -INFINITY);
+    mx = fmaxf(mx, (c + 1 < cols) ? v[k].y : -INFINITY);
+    mx = fmaxf(mx, (c + 2 < cols) ? v[k].z : -INFINITY);
+    mx = fmaxf(mx, (c + 3 < cols) ? v[k].w : -INFINITY);
+  }
+  mx = kh::wave_max(mx);
+  float sum = 0.f;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const int c = (lane + k * 64) * 4;
+    v[k].x = (c < cols) ? expf(v[k].x - mx) : 0.f;
+    v[k].y = (c + 1 < cols) ? expf(v[k].y - mx) : 0.f;
+    v[k].z = (c + 2 < cols) ? expf(v[k].z - mx) : 0.f;
+    v[k].w = (c + 3 < cols) ? expf(v[k].w - mx) : 0.f;
+    sum += (v[k].x + v[k].y) + (v[k].z + v[k].w);
+  }
+  sum = kh::wave_sum(sum);
+  const float inv = 1.0f / sum;
+  const __amdgpu_buffer_rsrc_t rsy = row_rsrc(y + (size_t)r * ldy, cols);
+#pragma unroll
+  for (int k = 0; k < NV; ++k) row_store4(rsy, (lane + k * 64) * 4, v[k].x * inv, v[k].y * inv, v[k].z * inv, v[k].w * inv);
+}
+
 __global__ __launch_bounds__(256) void softmax_part_kernel(const float *X, const int32_t *ids, float *Y,
                                                            MatrixDim d) {
   const int c = blockIdx.x * 256 + threadIdx.x;
@@ -299,6 +424,37 @@ __global__ __launch_bounds__(256) void find_row_max_id_kernel(const float *mat, 
   }
 }
 
+// one wave per row for short rows of a tall matrix (cols <= 256 * NV, 16-byte aligned rows): same result
+template <int NV>
+__global__ __launch_bounds__(256) void find_row_max_id_wave_kernel(const float *mat, float *vec_val, int32_t *vec_id, MatrixDim d) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= d.rows) return;
+  const __amdgpu_buffer_rsrc_t rs = row_rsrc(mat + (size_t)r * d.stride, d.cols);
+  float4 v[NV];
+#pragma unroll
+  for (int k = 0; k < NV; ++k) v[k] = row_load4(rs, (lane + k * 64) * 4);
+  MaxId m;
+  m.v = -1e21f;
+  m.i = -1;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const int c = (lane + k * 64) * 4;
+    const float e[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (c + j < d.cols && e[j] > m.v) {  // ascending columns per lane: the first maximum is kept
+        m.v = e[j];
+        m.i = c + j;
+      }
+  }
+  m = wave_best(m);
+  if (lane == 0) {
+    vec_id[r] = m.i;
+    if (vec_val) vec_val[r] = m.v;
+  }
+}
+
 __global__ void diff_xent_kernel(const int32_t *tgt, float *mat, float *log_post, MatrixDim d) {
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= d.rows) return;
@@ -334,7 +490,25 @@ __device__ __forceinline__ void xent_accum_block(const int32_t *tgt, const float
   if (t < 256) {
     double acc = 0.0;
     int correct = 0;
-    for (int r = t; r < rows; r += 256) {
+    int r = t;
+    // eight rows' loads in flight, added in the order of the plain loop below (a frame cache's worth of rows would
+    // otherwise be 128 memory round trips one after another on the last workgroup)
+    for (; r + 7 * 256 < rows; r += 8 * 256) {
+      float lp[8];
+      int32_t mi[8], tg[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        lp[u] = __hip_atomic_load(log_post + r + u * 256, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        mi[u] = __hip_atomic_load(max_id + r + u * 256, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        tg[u] = tgt[r + u * 256];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        acc += (double)lp[u];
+        correct += (mi[u] == tg[u]) ? 1 : 0;
+      }
+    }
+    for (; r < rows; r += 256) {
       acc += (double)__hip_atomic_load(log_post + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       correct += (__hip_atomic_load(max_id + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == tgt[r]) ? 1 : 0;
     }
@@ -482,6 +656,69 @@ __global__ __launch_bounds__(256) void xent_rows_vec_kernel(const float *post, c
   }
   xent_finish(tail, tgt, log_post, max_id, d.rows);
 }
+// pass 1 for short rows of a tall matrix (cols <= 256 * NV): one WAVE per row, four rows and ONE arrival per
+// workgroup.  Arg-max, target posterior and diff are what xent_rows_vec_kernel computes, and the totals are added up
+// by the same xent_accum_block: the same bits.
+template <int NV>
+__global__ __launch_bounds__(256) void xent_rows_wave_kernel(const float *post, const int32_t *tgt, float *diff, float *log_post,
+                                                             int32_t *max_id, MatrixDim d, int rows_per_wave, XentTail tail) {
+  const int lane = threadIdx.x & 63;
+  // (a wave takes rows_per_wave rows one after another: an arrival per row, or per four, is a queue on ONE word --
+  // about 90 adds per microsecond -- that 8192 workgroups of a frame cache spend longer in than in their rows)
+  for (int it = 0; it < rows_per_wave; ++it) {
+    const int r = (blockIdx.x * rows_per_wave + it) * 4 + (threadIdx.x >> 6);
+    if (r >= d.rows) break;
+    const int t = tgt[r];
+    const bool t_ok = (t >= 0 && t < d.cols);
+    const __amdgpu_buffer_rsrc_t rs = row_rsrc(post + (size_t)r * d.stride, d.cols);
+    const __amdgpu_buffer_rsrc_t rq = row_rsrc(diff + (size_t)r * d.stride, d.cols);
+    float4 v[NV];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) v[k] = row_load4(rs, (lane + k * 64) * 4);
+    MaxId m;
+    m.v = -1e21f;
+    m.i = -1;
+    float pt = 0.0f;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const int c = (lane + k * 64) * 4;
+      float e[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (c + j < d.cols) {
+          if (e[j] > m.v) {
+            m.v = e[j];
+            m.i = c + j;
+          }
+          if (c + j == t) {
+            pt = e[j];
+            e[j] -= 1.0f;
+          }
+        } else {
+          e[j] = 0.f;  // (row padding inside the last group of 4)
+        }
+      }
+      row_store4(rq, c, e[0], e[1], e[2], e[3]);
+    }
+    m = wave_best(m);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) pt += __shfl_xor(pt, o, 64);  // the target's posterior lives in exactly one lane
+    if (lane == 0) {
+      const float ptv = t_ok ? pt : 0.0f;
+      row_result_store(log_post, max_id, r, logf(ptv < 1e-20f ? 1e-20f : ptv), m.i);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's row results have reached the L2
+  // one arrival for the workgroup's rows, behind the waits of all its waves
+  __shared__ unsigned arrived;
+  __syncthreads();
+  if (threadIdx.x == 0) arrived = __hip_atomic_fetch_add(tail.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  if (arrived != gridDim.x - 1) return;
+  xent_accum_block(tgt, log_post, max_id, tail.counters, tail.loss, d.rows);
+  if (threadIdx.x == 0) __hip_atomic_store(tail.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // Softmax finish of the output layer's GEMM and Xent::EvalVec in one pass: the posteriors of a row
 // never leave the registers between the two (they are stored only when the caller wants them).
 // Arg-max, target posterior and diff are taken from the same rounded posteriors the two-kernel
@@ -639,6 +876,16 @@ int softmax_slabs_launch(hipStream_t st, float *y, int ldy, const float *x, int 
                          slab_stride, bias, cols, xf);
     return kh::launch_status();
   }
+  // Plain softmax of short rows: one wave per row.  Chosen by the row LENGTH only, so that a row's bits do not depend
+  // on how many rows share the call.
+  if (vec && !xent && nslab == 1 && !bias && cols <= 2048) {
+    const dim3 grid((rows + 3) / 4), block(256);
+    if (cols <= 512) hipLaunchKernelGGL((softmax_wave_kernel<2>), grid, block, 0, st, y, ldy, x, ldx, rows, cols);
+    else if (cols <= 1024) hipLaunchKernelGGL((softmax_wave_kernel<4>), grid, block, 0, st, y, ldy, x, ldx, rows, cols);
+    else if (cols <= 1536) hipLaunchKernelGGL((softmax_wave_kernel<6>), grid, block, 0, st, y, ldy, x, ldx, rows, cols);
+    else hipLaunchKernelGGL((softmax_wave_kernel<8>), grid, block, 0, st, y, ldy, x, ldx, rows, cols);
+    return kh::launch_status();
+  }
   if (vec && cols <= 4 * kSoftmaxThreads * 2)
     hipLaunchKernelGGL((softmax_vec_kernel<2>), dim3(rows), dim3(kSoftmaxThreads), 0, st, y, ldy, x, ldx, nslab,
                        slab_stride, bias, cols);
@@ -667,8 +914,37 @@ KH_EXPORT int hipF_add_row_sum_mat(khStream_t s, float alpha, const float *mat, 
   KH_REQUIRE(kh::dim_ok(d));
   if (d.cols == 0) return KH_OK;
   KH_REQUIRE(vec != nullptr && (d.rows == 0 || mat != nullptr));
-  hipLaunchKernelGGL(col_sums_kernel, dim3((d.cols + 63) / 64), dim3(1024), 0, kh::pick(s), alpha, mat, d, beta,
-                     vec);
+  hipStream_t st = kh::pick(s);
+  // Up to a few bunches of rows: one workgroup per 64 columns (the sums of a 256-frame bunch keep their bits).
+  // Taller: two stages over all compute units (col_sums_slab_kernel).
+  if (d.rows < 2048) {
+    hipLaunchKernelGGL(col_sums_kernel, dim3((d.cols + 63) / 64), dim3(1024), 0, st, alpha, mat, d, beta, vec);
+    return kh::launch_status();
+  }
+  const bool vec4 = d.stride % 4 == 0 && kh::aligned16(mat);
+  const int nv = !vec4 ? 0 : d.cols <= 256 ? 1 : d.cols <= 512 ? 2 : d.cols <= 1024 ? 4 : d.cols <= 1536 ? 6 : 8;
+  const int gx = vec4 ? (d.cols + 256 * nv - 1) / (256 * nv) : (d.cols + 63) / 64;
+  int nslab = 256 / gx;  // about one workgroup of 16 waves per compute unit; stage 2 then sums at most 256 rows
+  if (nslab > d.rows / 64) nslab = d.rows / 64;
+  if (nslab < 1) nslab = 1;
+  const int rows_per_slab = (d.rows + nslab - 1) / nslab;
+  nslab = (d.rows + rows_per_slab - 1) / rows_per_slab;
+  const int ldpart = (d.cols + 3) & ~3;
+  void *ws;
+  int rc = kh::ensure_workspace(st, (size_t)nslab * ldpart * sizeof(float), &ws);
+  if (rc != KH_OK) return rc;
+  const dim3 grid(gx, nslab), block(nv ? 1024 : 256);
+  float *part = (float *)ws;
+  switch (nv) {
+    case 0: hipLaunchKernelGGL(col_sums_slab_scalar_kernel, grid, block, 0, st, mat, d, rows_per_slab, part, ldpart); break;
+    case 1: hipLaunchKernelGGL(col_sums_slab_kernel<1>, grid, block, 0, st, mat, d, rows_per_slab, part, ldpart); break;
+    case 2: hipLaunchKernelGGL(col_sums_slab_kernel<2>, grid, block, 0, st, mat, d, rows_per_slab, part, ldpart); break;
+    case 4: hipLaunchKernelGGL(col_sums_slab_kernel<4>, grid, block, 0, st, mat, d, rows_per_slab, part, ldpart); break;
+    case 6: hipLaunchKernelGGL(col_sums_slab_kernel<6>, grid, block, 0, st, mat, d, rows_per_slab, part, ldpart); break;
+    default: hipLaunchKernelGGL(col_sums_slab_kernel<8>, grid, block, 0, st, mat, d, rows_per_slab, part, ldpart); break;
+  }
+  MatrixDim dp = {nslab, d.cols, ldpart};
+  hipLaunchKernelGGL(col_sums_kernel, dim3((d.cols + 63) / 64), dim3(1024), 0, st, alpha, (const float *)part, dp, beta, vec);
   return kh::launch_status();
 }
 
@@ -707,7 +983,16 @@ KH_EXPORT int hipF_find_row_max_id(khStream_t s, const float *mat, float *vec_va
   KH_REQUIRE(kh::dim_ok(d));
   if (d.rows == 0) return KH_OK;
   KH_REQUIRE(vec_id != nullptr && (d.cols == 0 || mat != nullptr));
-  hipLaunchKernelGGL(find_row_max_id_kernel, dim3(d.rows), dim3(256), 0, kh::pick(s), mat, vec_val, vec_id, d);
+  hipStream_t st = kh::pick(s);
+  if (d.rows >= 1024 && d.cols > 0 && d.cols <= 2048 && d.stride % 4 == 0 && kh::aligned16(mat)) {
+    const dim3 grid((d.rows + 3) / 4), block(256);
+    if (d.cols <= 512) hipLaunchKernelGGL(find_row_max_id_wave_kernel<2>, grid, block, 0, st, mat, vec_val, vec_id, d);
+    else if (d.cols <= 1024) hipLaunchKernelGGL(find_row_max_id_wave_kernel<4>, grid, block, 0, st, mat, vec_val, vec_id, d);
+    else if (d.cols <= 1536) hipLaunchKernelGGL(find_row_max_id_wave_kernel<6>, grid, block, 0, st, mat, vec_val, vec_id, d);
+    else hipLaunchKernelGGL(find_row_max_id_wave_kernel<8>, grid, block, 0, st, mat, vec_val, vec_id, d);
+    return kh::launch_status();
+  }
+  hipLaunchKernelGGL(find_row_max_id_kernel, dim3(d.rows), dim3(256), 0, st, mat, vec_val, vec_id, d);
   return kh::launch_status();
 }
 
@@ -731,7 +1016,16 @@ int xent_eval_launch(hipStream_t st, const float *post, const int32_t *tgt, floa
   tail.loss = loss;
   tail.ticket = ticket;
   const bool vec = (post != diff) && (d.stride % 4 == 0) && kh::aligned16(post) && kh::aligned16(diff);
-  if (vec && d.cols <= 4096)
+  if (vec && d.rows >= 1024 && d.cols <= 2048) {
+    // many short rows: a wave per row, one arrival per four rows
+    int rpw = d.rows / 1024;  // a few hundred to a thousand workgroups (arrivals), 1..8 rows per wave
+    rpw = rpw < 1 ? 1 : rpw > 8 ? 8 : rpw;
+    const dim3 grid((d.rows + 4 * rpw - 1) / (4 * rpw)), block(256);
+    if (d.cols <= 512) hipLaunchKernelGGL(xent_rows_wave_kernel<2>, grid, block, 0, st, post, tgt, diff, lp, mi, d, rpw, tail);
+    else if (d.cols <= 1024) hipLaunchKernelGGL(xent_rows_wave_kernel<4>, grid, block, 0, st, post, tgt, diff, lp, mi, d, rpw, tail);
+    else if (d.cols <= 1536) hipLaunchKernelGGL(xent_rows_wave_kernel<6>, grid, block, 0, st, post, tgt, diff, lp, mi, d, rpw, tail);
+    else hipLaunchKernelGGL(xent_rows_wave_kernel<8>, grid, block, 0, st, post, tgt, diff, lp, mi, d, rpw, tail);
+  } else if (vec && d.cols <= 4096)
     hipLaunchKernelGGL(xent_rows_vec_kernel<4>, dim3(d.rows), dim3(256), 0, st, post, tgt, diff, lp, mi, d, tail);
   else if (vec && d.cols <= 10240)
     hipLaunchKernelGGL(xent_rows_vec_kernel<10>, dim3(d.rows), dim3(256), 0, st, post, tgt, diff, lp, mi, d, tail);

@@ -148,7 +148,7 @@ def test_vector_broadcast_ops(hip, shape):
     assert (di.numpy() == -1).all()
 
 
-@pytest.mark.parametrize("shape", [(4321, 19), (1000, 990), (256, 2048), (256, 9000), (5, 1)])
+@pytest.mark.parametrize("shape", [(4321, 19), (1000, 990), (256, 2048), (256, 9000), (5, 1), (5000, 1320), (2048, 257), (9001, 1483)])
 def test_row_col_sums(hip, shape):
     h = hip
     R, C = shape
@@ -168,7 +168,7 @@ def test_row_col_sums(hip, shape):
     close(dv.numpy()[0], O.add_col_sum_mat(1.0, x, 0.0, np.zeros(R, f32)), 1e-5, 1e-5 * np.sqrt(C))
 
 
-@pytest.mark.parametrize("shape", [(100, 111), (256, 1483), (256, 9000), (3, 13001), (2, 1)])
+@pytest.mark.parametrize("shape", [(100, 111), (256, 1483), (256, 9000), (3, 13001), (2, 1), (4100, 1320), (3001, 19), (5, 2048), (7, 2049)])
 def test_softmax(hip, shape):
     h = hip
     x = rnd(shape, 11, 3.0)
@@ -182,6 +182,11 @@ def test_softmax(hip, shape):
     close(got.sum(1), np.ones(shape[0]), 1e-5)
     h.call("hipF_softmax", None, d.ptr, d.ptr, d.dim)  # in place
     np.testing.assert_allclose(d.numpy(), ref, rtol=1e-4, atol=1e-30)
+    # a row's bits do not depend on how many rows share the call
+    if shape[0] > 2:
+        sub = dev(h, x[1:3])
+        h.call("hipF_softmax", None, sub.ptr, sub.ptr, sub.dim)
+        assert np.array_equal(sub.numpy(), got[1:3])
 
 
 def test_softmax_part_and_argmax_ties(hip):
@@ -206,9 +211,20 @@ def test_softmax_part_and_argmax_ties(hip):
     h.call("hipF_softmax_part", None, d.ptr, ids2.ptr, y.ptr, d.dim)
     xx = x[:6]
     close(y.numpy()[:6], np.exp(xx - xx.max(1, keepdims=True)), 3e-6, 1e-30)
+    # the same rows inside a tall matrix (one wave per row there): same answers
+    for cols in (600, 1320, 2048):
+        tall = rnd((3000, cols), 15)
+        tall[:37, :600] = x
+        tall[:37, 600:] = -3e21
+        tall[2999, cols - 1] = tall[2999, 5] = 50.0
+        dtall = dev(h, tall)
+        idt, vt = h.DevMatrix(1, 3000, np.int32, pitched=False), h.DevMatrix(1, 3000, f32, pitched=False)
+        h.call("hipF_find_row_max_id", None, dtall.ptr, vt.ptr, idt.ptr, dtall.dim)
+        reft = O.find_row_max_id(tall)
+        assert (idt.numpy()[0] == reft).all() and idt.numpy()[0][2999] == 5 and idt.numpy()[0][6] == -1
 
 
-@pytest.mark.parametrize("shape", [(256, 1483), (256, 9000), (16, 17)])
+@pytest.mark.parametrize("shape", [(256, 1483), (256, 9000), (16, 17), (4100, 1320), (1026, 2048), (3000, 21)])
 def test_xent(hip, shape):
     h = hip
     R, C = shape

@@ -30,7 +30,7 @@ for counter, d, cfile in (("FETCH_SIZE", sys.argv[2], sys.argv[4]), ("WRITE_SIZE
         chunk = disp[pos:pos + c["launches"]]
         pos += c["launches"]
         assert all(c["kernel"] in k for k, _ in chunk), (c, chunk)
-        vals.append(sum(v for _, v in chunk) / len(chunk) * 1024.0)   # KiB counters
+        vals.append(sum(v for _, v in chunk) / c.get("calls", len(chunk)) * 1024.0)   # KiB counters, per call
     out.append(vals)
 print("| kernel (entry point) | shape | us / launch | algorithmic MB | GB/s | % of 8 TB/s | read MB (FETCH_SIZE x 2) | written MB (WRITE_SIZE) |")
 print("|---|---|---:|---:|---:|---:|---:|---:|")
