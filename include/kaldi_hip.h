@@ -309,6 +309,23 @@ int hipF_affine_update_fused(khStream_t s, int32_t N, int32_t O, int32_t I, cons
                              const float *W_in, int32_t ldw_in, float *W_out, int32_t ldw_out, float *corr,
                              int32_t ldcorr, float *bias, float *bcorr);
 
+/* Several dependent layers of a forward pass in ONE launch: layer i computes out_i = act(in_i * W_i^T + b_i) exactly
+ * as hipF_affine_forward(act, KH_TRANS, ...) would -- same kernels' tile code, same bits -- with in_i = out_{i-1}
+ * for i > 0.  The workgroups hand the activations of a row block to each other inside the launch (write-through
+ * stores, a counter per layer and row block, loads past the L1) instead of through a kernel boundary.  Taken only
+ * where every layer is the one-workgroup-per-compute-unit shape of a 256-frame bunch (same tile grid in every layer,
+ * at most one workgroup per compute unit, K a whole number of tiles, 16-byte aligned operands); anything else is
+ * run as `count` hipF_affine_forward launches by the call itself.  act: KH_ACT_NONE or KH_ACT_SIGMOID.  The
+ * library holds one set of hand-off counters per device: chains must not overlap in time on one device. */
+typedef struct {
+  int32_t O, I;
+  const float *in; int32_t ldin;
+  const float *W; int32_t ldw;
+  const float *bias;
+  float *out; int32_t ldout;
+} khAffineForward;
+int hipF_affine_forward_chain(khStream_t s, int act, int32_t N, int32_t count, const khAffineForward *layers);
+
 /* The updates of several layers in ONE launch: item i is exactly one hipF_affine_update_fused call (same
  * arguments, same bits), the items must not overlap in what they write.  For a training step that queues the
  * updates of all its <biasedlinearity> layers behind the back-propagation pass (each BiasedLinearity::Update,

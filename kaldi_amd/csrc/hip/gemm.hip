@@ -669,6 +669,88 @@ KH_EXPORT int hipF_affine_forward(khStream_t s, int act, int trans_w, int32_t N,
   return run_gemm<EPI_BIAS_ACT>(s, true, b_kmajor, p, true, act == KH_ACT_SOFTMAX);
 }
 
+namespace {
+struct ChainState {
+  unsigned *counters = nullptr;  // device: kMaxChain x 64 arrival counters, only ever growing
+  int *fail = nullptr;           // host-mapped: set by a workgroup whose wait ran out
+  unsigned epoch = 0;
+};
+ChainState &chain_state() {
+  static ChainState c;
+  return c;
+}
+}  // namespace
+
+KH_EXPORT int hipF_affine_forward_chain(khStream_t s, int act, int32_t N, int32_t count, const khAffineForward *layers) {
+  KH_CHECK_INIT();
+  KH_REQUIRE(act == KH_ACT_NONE || act == KH_ACT_SIGMOID);
+  KH_REQUIRE(N >= 0 && count >= 0 && (count == 0 || layers != nullptr));
+  for (int i = 0; i < count; ++i) {
+    const khAffineForward &l = layers[i];
+    KH_REQUIRE(l.O > 0 && l.I > 0 && l.in && l.W && l.bias && l.out && l.ldin >= l.I && l.ldout >= l.O && l.ldw >= l.I);
+    KH_REQUIRE(i == 0 || (l.in == layers[i - 1].out && l.ldin == layers[i - 1].ldout && l.I == layers[i - 1].O));
+  }
+  if (N == 0 || count == 0) return KH_OK;
+  static const bool off = getenv("KALDI_HIP_NO_CHAIN") != nullptr;  // for A/B measurements
+  hipStream_t st = kh::pick(s);
+  const int cus = kh::ctx().num_cu > 0 ? kh::ctx().num_cu : 256;
+  // the chained launch, where every layer qualifies
+  GemmChain g;
+  memset(&g, 0, sizeof(g));
+  bool ok = !off && count >= 2 && count <= kMaxChain && force_bm <= 0 && !row_invariant;
+  int cfg = -1;
+  double flops = 0.0;
+  for (int i = 0; ok && i < count; ++i) {
+    const khAffineForward &l = layers[i];
+    GemmParams p = base_params(N, l.O, l.I, l.in, l.ldin, l.W, l.ldw, l.out, l.ldout);
+    p.bias = l.bias;
+    p.act = act;
+    const bool vec = kh::aligned16(p.A) && kh::aligned16(p.B) && (p.lda % 4 == 0) && (p.ldb % 4 == 0);
+    Plan plan = make_plan(p.M, p.N, p.K, cus, true, false, true, KH_SCHED >= 2);
+    apply_plan(p, plan, true, true);
+    const int wk = kCfgs[plan.cfg].wk;
+    ok = vec && p.a_bytes > 0 && wk > 1 && plan.splitk == 1 && p.K % (kBK * wk) == 0 && p.tiles_m * p.tiles_n <= cus &&
+         p.tiles_m <= 64 && (cfg < 0 || (plan.cfg == cfg && p.tiles_m == g.p[0].tiles_m && p.tiles_n == g.p[0].tiles_n));
+    cfg = plan.cfg;
+    p.n_fastest = 0;
+    g.p[i] = p;
+    flops += 2.0 * p.M * p.N * p.K;
+  }
+  if (!ok) {
+    for (int i = 0; i < count; ++i) {
+      const khAffineForward &l = layers[i];
+      const int rc = hipF_affine_forward(s, act, KH_TRANS, N, l.O, l.I, l.in, l.ldin, l.W, l.ldw, l.bias, l.out, l.ldout);
+      if (rc != KH_OK) return rc;
+    }
+    return KH_OK;
+  }
+  ChainState &cs = chain_state();
+  if (!cs.counters) {
+    KH_HIP(hipMalloc((void **)&cs.counters, kMaxChain * 64 * sizeof(unsigned)));
+    KH_HIP(hipMemsetAsync(cs.counters, 0, kMaxChain * 64 * sizeof(unsigned), st));
+    KH_HIP(hipHostMalloc((void **)&cs.fail, sizeof(int), hipHostMallocMapped));
+    *cs.fail = 0;
+  }
+  if (*cs.fail != 0) {
+    snprintf(kh::ctx().last_msg, sizeof(kh::ctx().last_msg), "hipF_affine_forward_chain: a hand-off wait ran out in layer %d of an earlier launch",
+             *cs.fail);
+    return KH_ERR_INVALID_ARG;
+  }
+  if (cs.epoch >= (1u << 24)) {  // counters start over long before they could wrap
+    KH_HIP(hipMemsetAsync(cs.counters, 0, kMaxChain * 64 * sizeof(unsigned), st));
+    cs.epoch = 0;
+  }
+  g.n = count;
+  g.epoch = ++cs.epoch;
+  g.counters = cs.counters;
+  g.fail = cs.fail;
+  {
+    TimedLaunch tl(st, flops);
+    launch_forward_chain(st, g, cfg);
+  }
+  return kh::launch_status();
+}
+
 KH_EXPORT int hipF_affine_forward_xent(khStream_t s, int trans_w, int32_t N, int32_t O, int32_t I, const float *in,
                                        int32_t ldin, const float *W, int32_t ldw, const float *bias, float *post,
                                        int32_t ldpost, int write_post, const int32_t *tgt, float *diff, int32_t lddiff,

@@ -97,6 +97,17 @@ struct GemmGroup {
 void launch_update_group(hipStream_t st, const GemmGroup &g, bool big);  // big: 128 x 128 tiles, else 64 x 64
 void launch_grad_group(hipStream_t st, const GemmGroup &g, bool big);    // the same launch with the EPI_GRAD epilogue
 
+// Dependent forward products in one launch (gemm_chain_kernel below).
+constexpr int kMaxChain = 8;
+struct GemmChain {
+  int n;
+  unsigned epoch;
+  unsigned *counters;  // [kMaxChain][tiles_m]
+  int *fail;
+  GemmParams p[kMaxChain];
+};
+void launch_forward_chain(hipStream_t st, const GemmChain &g, int cfg);
+
 // launches the main kernel for tile configuration `cfg` (index into the planner's table) and operand layout
 template <int EPI>
 void launch_layout(hipStream_t st, const GemmParams &p, int cfg, bool vec, bool a_kmajor, bool b_kmajor);
@@ -156,7 +167,7 @@ __device__ __forceinline__ float epi_value(const GemmParams &p, float acc, float
   return acc;
 }
 
-template <int EPI>
+template <int EPI, bool SC1 = false>
 __device__ __forceinline__ void epi_store(const GemmParams &p, int row, int col, float val, int ks) {
   if (EPI == EPI_SLAB) {
     p.C[(size_t)ks * p.slab_stride + (size_t)row * p.ldc + col] = val;
@@ -164,7 +175,12 @@ __device__ __forceinline__ void epi_store(const GemmParams &p, int row, int col,
     float *c = p.C + (size_t)row * p.ldc + col;
     *c = (p.beta == 0.f) ? p.alpha * val : p.alpha * val + p.beta * *c;
   } else if (EPI == EPI_BIAS_ACT || EPI == EPI_DSIG) {
-    p.C[(size_t)row * p.ldc + col] = val;
+#if defined(KH_CHAIN_PROBE) && KH_CHAIN_PROBE >= 2
+    __hip_atomic_store(p.C + (size_t)row * p.ldc + col, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (sc1 store)
+#else
+    if (SC1) __hip_atomic_store(p.C + (size_t)row * p.ldc + col, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else p.C[(size_t)row * p.ldc + col] = val;
+#endif
   } else if (EPI == EPI_UPDATE) {
     float c = p.alpha * val;
     if (p.mom != 0.f) c = kh::mul_add(p.mom, p.C[(size_t)row * p.ldc + col], c);
@@ -216,7 +232,9 @@ constexpr int gemm_lds_floats() {
 // congruent to blockIdx.x modulo 8 for the XCD-aware decode below to keep its meaning).
 // NW = 8 (only with WK = 1): a 512-thread workgroup, waves arranged 2 x 4 over the tile.
 // KTAIL: the variant for K ranges that end inside a tile (see mask_tail below).
-template <int BM, int BN, int BK, int WK, bool A_KMAJOR, bool B_KMAJOR, int EPI, bool VEC, int NW = 4, bool KTAIL = false>
+// CHAIN: this product runs inside a launch that also holds its producer (gemm_chain_kernel): operand A is loaded past
+// the L1 (sc1) and the results are stored write-through (sc1), the two halves of a hand-off between compute units.
+template <int BM, int BN, int BK, int WK, bool A_KMAJOR, bool B_KMAJOR, int EPI, bool VEC, int NW = 4, bool KTAIL = false, bool CHAIN = false>
 __device__ __forceinline__ void gemm_tile(const GemmParams &p, float *lds, const int bid, const int nblk) {
   constexpr int NT = 64 * NW;
   static_assert(NW == 4 || (NW == 8 && WK == 1), "4 waves, or 8 waves without a K split over waves");
@@ -318,6 +336,22 @@ __device__ __forceinline__ void gemm_tile(const GemmParams &p, float *lds, const
     const v4i r = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0);
     return make_float4(__int_as_float(r.x), __int_as_float(r.y), __int_as_float(r.z), __int_as_float(r.w));
   };
+#ifdef KH_CHAIN_PROBE
+  // Diagnostic build (make alt ALT=-DKH_CHAIN_PROBE=1 or =2): what handing the activations from one layer's workgroups to the
+  // next layer's INSIDE one launch would cost the kernels themselves -- the activation operand (A of the forward and
+  // back-propagation products) is loaded past the L1 (sc1) and, with =2, the outputs are stored write-through (sc1; 4 bytes a
+  // lane in this epilogue's layout), as such a hand-off needs; the weight panels stay on the cached path.  No synchronisation is added: the launches stay.
+  auto buf_load_a = [&](const __amdgpu_buffer_rsrc_t &rs, int voff, int soff) {
+    if (EPI != EPI_BIAS_ACT && EPI != EPI_DSIG) return buf_load(rs, voff, soff);
+    const v4i r = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 16);
+    return make_float4(__int_as_float(r.x), __int_as_float(r.y), __int_as_float(r.z), __int_as_float(r.w));
+  };
+#else
+  auto buf_load_a = [&](const __amdgpu_buffer_rsrc_t &rs, int voff, int soff) {
+    const v4i r = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, CHAIN ? 16 : 0);
+    return make_float4(__int_as_float(r.x), __int_as_float(r.y), __int_as_float(r.z), __int_as_float(r.w));
+  };
+#endif
   // two products in one pass (EPI_RBM, p.nk1 > 0): K-tile kt >= nk1 is tile kt - nk1 of the second pair of operands
   constexpr bool DUAL_EPI = (EPI == EPI_RBM);
   const int nk1 = DUAL_EPI ? p.nk1 : 0;
@@ -361,7 +395,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams &p, float *lds, const
       return;
     }
 #pragma unroll
-    for (int u = 0; u < A_UNITS; ++u) ra[u] = buf_load(rsrc_a, oa[u], kt * a_step);
+    for (int u = 0; u < A_UNITS; ++u) ra[u] = buf_load_a(rsrc_a, oa[u], kt * a_step);
 #pragma unroll
     for (int u = 0; u < B_UNITS; ++u) rb[u] = buf_load(rsrc_b, ob[u], kt * b_step);
   };
@@ -517,7 +551,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams &p, float *lds, const
       v = (c < A_UNITS) ? buf_load(rsrc_a2, oa[c < A_UNITS ? c : 0], (kt - nk1) * a_step)
                         : buf_load(rsrc_b2, ob[c < A_UNITS ? 0 : c - A_UNITS], (kt - nk1) * b_step);
     else
-      v = (c < A_UNITS) ? buf_load(rsrc_a, oa[c < A_UNITS ? c : 0], kt * a_step)
+      v = (c < A_UNITS) ? buf_load_a(rsrc_a, oa[c < A_UNITS ? c : 0], kt * a_step)
                         : buf_load(rsrc_b, ob[c < A_UNITS ? 0 : c - A_UNITS], kt * b_step);
     if (c < A_UNITS) ra[c] = v; else rb[c - A_UNITS] = v;
   };
@@ -969,7 +1003,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams &p, float *lds, const
             p.Wout[(size_t)row * p.ldwout + col] = -p.lr * c + wv;
           } else if (row < p.M && col < p.N) {
             if (DUAL_EPI && nk1 > 0) rbm_dual_store(p, row, col, acc1[DUAL_EPI ? i : 0][DUAL_EPI ? q : 0][r], acc[i][q][r]);
-            else epi_store<EPI>(p, row, col, epi_value<EPI>(p, acc[i][q][r], epi_aux<EPI>(p, row, col)), ks);
+            else epi_store<EPI, CHAIN>(p, row, col, epi_value<EPI>(p, acc[i][q][r], epi_aux<EPI>(p, row, col)), ks);
           }
         }
   } else {
@@ -1022,7 +1056,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams &p, float *lds, const
         const int r = wk * RS + rr;
         const int row = m0 + wm0 + (a / TN) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
         const int col = n0 + wn0 + (a % TN) * 32 + li;
-        if (row < p.M && col < p.N) epi_store<EPI>(p, row, col, sum[a][rr], ks);
+        if (row < p.M && col < p.N) epi_store<EPI, CHAIN>(p, row, col, sum[a][rr], ks);
       }
   }
   KH_STAMP(6);
@@ -1267,6 +1301,56 @@ void launch_update_group(hipStream_t st, const GemmGroup &g, bool big) {
   else hipLaunchKernelGGL(gemm_update_group_kernel<false>, dim3(g.first[g.n]), dim3(256), 0, st, g);
 }
 #endif  // KHG_DEFINE_UPDATE_GROUP
+
+#ifdef KHG_DEFINE_CHAIN
+// Several dependent forward products (hidden layers: bias + sigmoid epilogue) in ONE launch, one workgroup per
+// compute unit and tile, the same tile in every layer.  A workgroup's tile of layer l needs the whole rows of layer
+// l - 1's output for its row block, i.e. the tiles of the tiles_n workgroups that share its row block: each of them
+// stores its tile write-through, waits for the stores, and adds 1 to the row block's counter of that layer; a
+// consumer polls that counter (one lane, past the L1) until all tiles_n have arrived, and loads the activations
+// past the L1.  Counters only grow: launch number `epoch` waits for tiles_n * epoch.  The grid (one tile each,
+// at most one round of co-resident workgroups) is checked by the host; a poll that runs out of patience sets *fail
+// and goes on, so the launch always ends.
+
+template <int BM, int BN, int WK>
+__global__ __launch_bounds__(256) void gemm_chain_kernel(GemmChain g) {
+  __shared__ __attribute__((aligned(16))) float lds[gemm_lds_floats<BM, BN, kBK, WK, true, true>()];
+  const int nblk = gridDim.x;
+  int L = blockIdx.x;  // same decode as gemm_tile (n_fastest == 0, no K split over workgroups)
+  if ((nblk & 7) == 0) L = (L & 7) * (nblk >> 3) + (L >> 3);
+  const int tiles_m = g.p[0].tiles_m, tiles_n = g.p[0].tiles_n;
+  const int mi = L % tiles_m;
+  for (int l = 0; l < g.n; ++l) {
+    if (l > 0) {
+      if (threadIdx.x == 0) {
+        const unsigned want = (unsigned)tiles_n * g.epoch;
+        const unsigned *ctr = g.counters + (l - 1) * tiles_m + mi;
+        int patience = 1 << 22;
+        while ((int)(__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want) < 0) {
+          __builtin_amdgcn_s_sleep(2);
+          if (--patience == 0) {
+            *g.fail = l;
+            break;
+          }
+        }
+      }
+      __syncthreads();
+    }
+    gemm_tile<BM, BN, kBK, WK, true, true, EPI_BIAS_ACT, true, 4, false, true>(g.p[l], lds, blockIdx.x, nblk);
+    if (l + 1 < g.n) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's write-through stores have reached the L2
+      __syncthreads();
+      if (threadIdx.x == 0) __hip_atomic_fetch_add(g.counters + l * tiles_m + mi, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
+void launch_forward_chain(hipStream_t st, const GemmChain &g, int cfg) {
+  const int nblk = g.p[0].tiles_m * g.p[0].tiles_n;
+  if (cfg == 4) hipLaunchKernelGGL((gemm_chain_kernel<32, 64, 2>), dim3(nblk), dim3(256), 0, st, g);
+  else hipLaunchKernelGGL((gemm_chain_kernel<32, 32, 4>), dim3(nblk), dim3(256), 0, st, g);
+}
+#endif  // KHG_DEFINE_CHAIN
 
 #ifdef KHG_DEFINE_GRAD_GROUP
 // The same grouped launch for the data-parallel form of the step: every problem writes its raw product

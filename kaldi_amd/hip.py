@@ -39,6 +39,13 @@ class AffineGradient(ctypes.Structure):
                 ("gW", ctypes.c_void_p), ("ldg", ctypes.c_int32), ("gb", ctypes.c_void_p)]
 
 
+class AffineForward(ctypes.Structure):
+    """khAffineForward: one layer of hipF_affine_forward_chain."""
+    _fields_ = [("O", ctypes.c_int32), ("I", ctypes.c_int32), ("in_", ctypes.c_void_p), ("ldin", ctypes.c_int32),
+                ("W", ctypes.c_void_p), ("ldw", ctypes.c_int32), ("bias", ctypes.c_void_p), ("out", ctypes.c_void_p),
+                ("ldout", ctypes.c_int32)]
+
+
 class SgdSegment(ctypes.Structure):
     """khSgdSegment: one run of elements of hipF_sgd_apply_segments with its hyper-parameters."""
     _fields_ = [("begin", ctypes.c_size_t), ("end", ctypes.c_size_t), ("gscale", ctypes.c_float),

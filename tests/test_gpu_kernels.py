@@ -585,6 +585,42 @@ def test_affine_update_group_equals_single_launches(hip, mom):
         assert np.array_equal(s["Wb"].numpy(), w)
 
 
+@pytest.mark.parametrize("width,nl", [(2048, 6), (1024, 3)])
+def test_affine_forward_chain_equals_separate_launches(hip, width, nl):
+    """hipF_affine_forward_chain (dependent hidden layers in one launch, activations handed from workgroup to workgroup
+    inside it) against one hipF_affine_forward launch per layer: the same bits in every layer's output, over several
+    launches (the hand-off counters only grow) with fresh inputs; a chain the one-launch form does not take (a first
+    layer whose K ends inside a tile) runs as separate launches inside the call and gives the same bits too."""
+    import ctypes
+    h = hip
+    N = 256
+    rs = np.random.RandomState(width)
+    dims = [width] * (nl + 1)
+    for dims in ([width] * (nl + 1), [1320] + [width] * 2):
+        n = len(dims) - 1
+        x = h.DevMatrix.from_numpy(rs.randn(N, dims[0]).astype(f32))
+        Ws = [h.DevMatrix.from_numpy((0.05 * rs.randn(dims[i + 1], dims[i])).astype(f32)) for i in range(n)]
+        bs = [dev(h, (0.1 * rs.randn(dims[i + 1])).astype(f32), False) for i in range(n)]
+        act_a = [x] + [h.DevMatrix(N, dims[i + 1]) for i in range(n)]
+        act_b = [x] + [h.DevMatrix(N, dims[i + 1]) for i in range(n)]
+        items = (h.AffineForward * n)()
+        for i in range(n):
+            items[i] = h.AffineForward(dims[i + 1], dims[i], act_b[i]._p.value, act_b[i].stride, Ws[i]._p.value, Ws[i].stride,
+                                       bs[i]._p.value, act_b[i + 1]._p.value, act_b[i + 1].stride)
+        for rep in range(4):
+            x.set(rs.randn(N, dims[0]).astype(f32))
+            for i in range(n):
+                h.call("hipF_affine_forward", None, h.ACT_SIGMOID, h.TRANS, N, dims[i + 1], dims[i], act_a[i].ptr, act_a[i].stride,
+                       Ws[i].ptr, Ws[i].stride, bs[i].ptr, act_a[i + 1].ptr, act_a[i + 1].stride)
+            h.call("hipF_affine_forward_chain", None, h.ACT_SIGMOID, N, n, ctypes.cast(items, ctypes.c_void_p))
+            for i in range(1, n + 1):
+                assert np.array_equal(act_a[i].numpy(), act_b[i].numpy()), (dims, rep, i)
+    # layers that do not follow one another are refused
+    items[1].in_ = x._p.value
+    with pytest.raises(h.HipError):
+        h.call("hipF_affine_forward_chain", None, h.ACT_SIGMOID, N, n, ctypes.cast(items, ctypes.c_void_p))
+
+
 def test_affine_gradient_group_and_sgd_apply_segments(hip):
     """The two halves of the sharded data-parallel step.
     hipF_affine_gradient_group: gW = e^T * in with the weight matrix's row pitch and gb = colsum(e) for several layers in

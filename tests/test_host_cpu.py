@@ -31,7 +31,8 @@ def test_public_header_is_plain_c_and_struct_layouts_match_the_binding(tmp_path)
     kaldi_amd/hip.py assumes."""
     import kaldi_amd.hip as h
     cname = {"in_": "in"}
-    structs = [("khAffineUpdate", h.AffineUpdate), ("khAffineGradient", h.AffineGradient), ("khSgdSegment", h.SgdSegment)]
+    structs = [("khAffineUpdate", h.AffineUpdate), ("khAffineGradient", h.AffineGradient), ("khSgdSegment", h.SgdSegment),
+               ("khAffineForward", h.AffineForward)]
     lines = ['  printf("%zu\\n", sizeof(MatrixDim));\n']
     for cn, py in structs:
         lines.append('  printf("%%zu\\n", sizeof(%s));\n' % cn)
