@@ -309,6 +309,16 @@ int hipF_affine_update_fused(khStream_t s, int32_t N, int32_t O, int32_t I, cons
                              const float *W_in, int32_t ldw_in, float *W_out, int32_t ldw_out, float *corr,
                              int32_t ldcorr, float *bias, float *bcorr);
 
+/* hipF_affine_forward(KH_ACT_SIGMOID, KH_TRANS, ...) and hipF_binarize_probs_rand on its output in ONE launch -- the
+ * positive phase of an RBM CD-1 step with Bernoulli hidden units (Rbm::Propagate, nnet-rbm.h:136-145, followed by
+ * CuRand::BinarizeProbs, cu-rand-inl.h:139-169): probs = sigmoid(in * W^T + b), states = (probs > u) ? 1 : 0 with one
+ * HybridTaus draw u per element from the state arrays z1..z4, which are indexed like probs (r * ldprobs + c) and
+ * advanced exactly as hipF_binarize_probs_rand advances them: same probabilities, same states, same generator
+ * state afterwards as the two calls.  ldstates must equal ldprobs. */
+int hipF_affine_forward_sample(khStream_t s, int32_t N, int32_t O, int32_t I, const float *in, int32_t ldin,
+                               const float *W, int32_t ldw, const float *bias, float *probs, int32_t ldprobs,
+                               float *states, int32_t ldstates, uint32_t *z1, uint32_t *z2, uint32_t *z3, uint32_t *z4);
+
 /* Several dependent layers of a forward pass in ONE launch: layer i computes out_i = act(in_i * W_i^T + b_i) exactly
  * as hipF_affine_forward(act, KH_TRANS, ...) would -- same kernels' tile code, same bits -- with in_i = out_{i-1}
  * for i > 0.  The workgroups hand the activations of a row block to each other inside the launch (write-through

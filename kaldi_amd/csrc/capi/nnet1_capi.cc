@@ -213,10 +213,10 @@ int rbm1_cd1_bunch(void *h, const float *feats_dev, int ld, int rows, int cols) 
   RbmBase &rbm = dynamic_cast<RbmBase &>(*t->nnet.Layer(0));
   // a window onto the caller's rows (read-only here), like a bunch taken out of the cache
   t->pos_vis.AttachView(const_cast<float *>(feats_dev), rows, cols, ld);
-  rbm.Propagate(t->pos_vis, &t->pos_hid);
   if (rbm.HidType() == Rbm::BERNOULLI) {
-    t->cu_rand.BinarizeProbs(t->pos_hid, &t->neg_hid);
+    rbm.PropagateSample(t->pos_vis, &t->cu_rand, &t->pos_hid, &t->neg_hid);
   } else {
+    rbm.Propagate(t->pos_vis, &t->pos_hid);
     t->neg_hid.CopyFromMat(t->pos_hid);
     t->cu_rand.AddGaussNoise(&t->neg_hid);
   }

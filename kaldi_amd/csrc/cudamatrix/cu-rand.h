@@ -54,6 +54,12 @@ class CuRand {
     states->Resize(probs.NumRows(), probs.NumCols());
     CU_SAFE_CALL(hipF_binarize_probs_rand(S(), states->Data(), probs.Data(), z_[0], z_[1], z_[2], z_[3], probs.Dim()));
   }
+  /// The four state arrays for matrices shaped like `m` (seeded first if the size has changed), for a kernel that
+  /// draws inside another operation's launch; indexed like m (row * Stride() + column).
+  void States(const CuMatrix<Real> &m, uint32 **z1, uint32 **z2, uint32 **z3, uint32 **z4) {
+    Prepare(m);
+    *z1 = z_[0]; *z2 = z_[1]; *z3 = z_[2]; *z4 = z_[3];
+  }
   /// tgt += gscale * N(0,1), in one pass
   void AddGaussNoise(CuMatrix<Real> *tgt, Real gscale = 1.0) {
     CuProfileScope p(__func__);

@@ -177,6 +177,24 @@ __device__ __forceinline__ void mse_row_and_total(const float *a_row, const floa
   }
 }
 
+// Per-element HybridTaus generator (three Tausworthe steps xor one LCG step): restates the reference's
+// src/cudamatrix/cu-randkernels.cu:44-71 so that equal states give equal draws.  Uniform in (0,1): the product is
+// formed in double and rounded to float; values that round to 0 or 1 are rejected and redrawn.
+__device__ __forceinline__ uint32_t taus_step(uint32_t &z, int s1, int s2, int s3, uint32_t m) {
+  const uint32_t b = (((z << s1) ^ z) >> s2);
+  return z = (((z & m) << s3) ^ b);
+}
+__device__ __forceinline__ uint32_t lcg_step(uint32_t &z) { return z = 1664525u * z + 1013904223u; }
+__device__ __forceinline__ float hybrid_taus(uint32_t &z1, uint32_t &z2, uint32_t &z3, uint32_t &z4) {
+  float v;
+  do {
+    const uint32_t bits = taus_step(z1, 13, 19, 12, 4294967294u) ^ taus_step(z2, 2, 25, 4, 4294967288u) ^
+                          taus_step(z3, 3, 11, 17, 4294967280u) ^ lcg_step(z4);
+    v = (float)(2.3283064365387e-10 * (double)bits);
+  } while (!(v > 0.0f && v < 1.0f));
+  return v;
+}
+
 // 1/(1+exp(-x)) in fp32.  expf() here is the correctly scaled library call (not the fast
 // intrinsic) so results stay within a few ulp of the reference's double evaluation.
 __device__ __forceinline__ float sigmoidf(float x) { return 1.0f / (1.0f + expf(-x)); }

@@ -669,6 +669,22 @@ KH_EXPORT int hipF_affine_forward(khStream_t s, int act, int trans_w, int32_t N,
   return run_gemm<EPI_BIAS_ACT>(s, true, b_kmajor, p, true, act == KH_ACT_SOFTMAX);
 }
 
+KH_EXPORT int hipF_affine_forward_sample(khStream_t s, int32_t N, int32_t O, int32_t I, const float *in, int32_t ldin,
+                                         const float *W, int32_t ldw, const float *bias, float *probs, int32_t ldprobs,
+                                         float *states, int32_t ldstates, uint32_t *z1, uint32_t *z2, uint32_t *z3,
+                                         uint32_t *z4) {
+  KH_CHECK_INIT();
+  KH_REQUIRE(N >= 0 && O > 0 && I > 0);
+  if (N == 0) return KH_OK;
+  KH_REQUIRE(in && W && bias && probs && states && z1 && z2 && z3 && z4 && ldin >= I && ldw >= I && ldprobs >= O && ldstates == ldprobs);
+  GemmParams p = base_params(N, O, I, in, ldin, W, ldw, probs, ldprobs);
+  p.bias = bias;
+  p.act = KH_ACT_SIGMOID;
+  p.C2 = states;
+  p.z1 = z1; p.z2 = z2; p.z3 = z3; p.z4 = z4;
+  return run_gemm<EPI_BIAS_SAMPLE>(s, true, true, p, /*allow_split=*/false);
+}
+
 namespace {
 struct ChainState {
   unsigned *counters = nullptr;  // device: kMaxChain x 64 arrival counters, only ever growing

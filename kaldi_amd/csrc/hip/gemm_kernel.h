@@ -26,7 +26,8 @@ enum Epi {
   EPI_DSIG = 3,    // C = acc * y * (1 - y)
   EPI_UPDATE = 4,  // corr = g*acc + mom*corr ; W = W - l2*W - lr*corr
   EPI_RBM = 5,     // dW = g*acc + dW - lrl2*W ; W += dW
-  EPI_GRAD = 6     // C = alpha*acc, the update product without the weight step (data-parallel gradient), 16-byte stores
+  EPI_GRAD = 6,    // C = alpha*acc, the update product without the weight step (data-parallel gradient), 16-byte stores
+  EPI_BIAS_SAMPLE = 7  // C = sigmoid(bias[col] + acc) and C2 = (C > uniform) ? 1 : 0 with one HybridTaus draw per element
 };
 
 struct GemmParams {
@@ -57,6 +58,9 @@ struct GemmParams {
   int ldwout;
   float lr, l2, mom;
   int act;
+  // EPI_BIAS_SAMPLE: the sampled states and the per-element generator state, all indexed like C (r * ldc + c)
+  float *C2;
+  unsigned *z1, *z2, *z3, *z4;
   int dyn_lds;     // extra LDS bytes to request at launch (caps how many workgroups share a compute unit)
   // EPI_UPDATE: footprints of W / Wout / C (< 2 GiB) when the epilogue may use 16-byte buffer accesses on them
   // (all 16-byte aligned, leading dimensions and N multiples of 4), else 0: see the epilogue
@@ -149,7 +153,7 @@ void launch_reduce(hipStream_t st, const GemmParams &p, const float *slabs, int 
 // column are clamped into the matrix (elements outside are computed but never stored).
 template <int EPI>
 __device__ __forceinline__ float epi_aux(const GemmParams &p, int row, int col) {
-  if (EPI == EPI_BIAS_ACT) return p.bias[min(col, p.N - 1)];
+  if (EPI == EPI_BIAS_ACT || EPI == EPI_BIAS_SAMPLE) return p.bias[min(col, p.N - 1)];
   if (EPI == EPI_DSIG) return p.y[(size_t)min(row, p.M - 1) * p.ldy + min(col, p.N - 1)];
   return 0.f;
 }
@@ -164,6 +168,7 @@ __device__ __forceinline__ float epi_value(const GemmParams &p, float acc, float
     return p.act == KH_ACT_SIGMOID ? kh::sigmoidf(v) : v;
   }
   if (EPI == EPI_DSIG) return aux * (1.0f - aux) * acc;
+  if (EPI == EPI_BIAS_SAMPLE) return kh::sigmoidf(acc + aux);
   return acc;
 }
 
@@ -197,6 +202,14 @@ __device__ __forceinline__ void epi_store(const GemmParams &p, int row, int col,
     p.Wout[(size_t)row * p.ldwout + col] = d + wv;
   } else if (EPI == EPI_GRAD) {
     p.C[(size_t)row * p.ldc + col] = p.alpha * val;
+  } else if (EPI == EPI_BIAS_SAMPLE) {
+    // (the form with one round trip per element; the tiles whose waves split K fetch the states of all their
+    // elements together, see the epilogue)
+    const size_t idx = (size_t)row * p.ldc + col;
+    unsigned a = p.z1[idx], b = p.z2[idx], c = p.z3[idx], d = p.z4[idx];
+    p.C[idx] = val;
+    p.C2[idx] = (val > kh::hybrid_taus(a, b, c, d)) ? 1.0f : 0.0f;
+    p.z1[idx] = a; p.z2[idx] = b; p.z3[idx] = c; p.z4[idx] = d;
   }
 }
 
@@ -259,7 +272,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams &p, float *lds, const
   // The products of the dependent chain (forward, back-propagation) outrank the weight updates that
   // fill the compute units beside them: where waves of both share a SIMD, the chain's issue first.
 #ifndef KH_NO_CHAIN_PRIO
-  if (EPI != EPI_UPDATE && EPI != EPI_RBM && EPI != EPI_GRAD) __builtin_amdgcn_s_setprio(3);
+  if (EPI != EPI_UPDATE && EPI != EPI_RBM && EPI != EPI_GRAD) __builtin_amdgcn_s_setprio(3);  // (EPI_BIAS_SAMPLE included)
 #endif
   // Which way the run walks decides which operand an XCD reads whole: down the rows first it covers every row
   // tile of a few column tiles (all of A, a slice of B); along the columns first the other way round -- the host
@@ -1034,6 +1047,24 @@ __device__ __forceinline__ void gemm_tile(const GemmParams &p, float *lds, const
         const int r = wk * RS + rr;
         aux[a][rr] = epi_aux<EPI>(p, m0 + wm0 + (a / TN) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, n0 + wn0 + (a % TN) * 32 + li);
       }
+    // EPI_BIAS_SAMPLE: the generator states of this lane's elements, all in flight together with the bias (elements
+    // past the matrix edge read the last valid one and are never stored)
+    unsigned zs[EPI == EPI_BIAS_SAMPLE ? NACC : 1][EPI == EPI_BIAS_SAMPLE ? RS : 1][4];
+    if (EPI == EPI_BIAS_SAMPLE) {
+#pragma unroll
+      for (int a = 0; a < NACC; ++a)
+#pragma unroll
+        for (int rr = 0; rr < RS; ++rr) {
+          const int r = wk * RS + rr;
+          const int row = min(m0 + wm0 + (a / TN) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, p.M - 1);
+          const int col = min(n0 + wn0 + (a % TN) * 32 + li, p.N - 1);
+          const size_t idx = (size_t)row * p.ldc + col;
+          zs[EPI == EPI_BIAS_SAMPLE ? a : 0][EPI == EPI_BIAS_SAMPLE ? rr : 0][0] = p.z1[idx];
+          zs[EPI == EPI_BIAS_SAMPLE ? a : 0][EPI == EPI_BIAS_SAMPLE ? rr : 0][1] = p.z2[idx];
+          zs[EPI == EPI_BIAS_SAMPLE ? a : 0][EPI == EPI_BIAS_SAMPLE ? rr : 0][2] = p.z3[idx];
+          zs[EPI == EPI_BIAS_SAMPLE ? a : 0][EPI == EPI_BIAS_SAMPLE ? rr : 0][3] = p.z4[idx];
+        }
+    }
     lds_barrier();  // (not __syncthreads: the loads just issued stay in flight across it)
     float sum[NACC][RS];
 #pragma unroll
@@ -1056,7 +1087,18 @@ __device__ __forceinline__ void gemm_tile(const GemmParams &p, float *lds, const
         const int r = wk * RS + rr;
         const int row = m0 + wm0 + (a / TN) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
         const int col = n0 + wn0 + (a % TN) * 32 + li;
-        if (row < p.M && col < p.N) epi_store<EPI, CHAIN>(p, row, col, sum[a][rr], ks);
+        if (EPI == EPI_BIAS_SAMPLE) {
+          unsigned *z = zs[EPI == EPI_BIAS_SAMPLE ? a : 0][EPI == EPI_BIAS_SAMPLE ? rr : 0];
+          const float u = kh::hybrid_taus(z[0], z[1], z[2], z[3]);
+          if (row < p.M && col < p.N) {
+            const size_t idx = (size_t)row * p.ldc + col;
+            p.C[idx] = sum[a][rr];
+            p.C2[idx] = (sum[a][rr] > u) ? 1.0f : 0.0f;
+            p.z1[idx] = z[0]; p.z2[idx] = z[1]; p.z3[idx] = z[2]; p.z4[idx] = z[3];
+          }
+        } else if (row < p.M && col < p.N) {
+          epi_store<EPI, CHAIN>(p, row, col, sum[a][rr], ks);
+        }
       }
   }
   KH_STAMP(6);
@@ -1408,7 +1450,7 @@ void launch_cfg(hipStream_t st, const GemmParams &p, bool vec) {
   // K ends inside a tile: the variant that runs the tail in the fast loop (forward and back-propagation products on
   // the tiles whose waves split K -- the shapes of a 256-row bunch; K = 440, 1320, 9000 of the RM- and
   // Switchboard-sized nets)
-  if constexpr ((EPI == EPI_BIAS_ACT || EPI == EPI_DSIG) && WK > 1 && KH_SCHED >= 2) {
+  if constexpr ((EPI == EPI_BIAS_ACT || EPI == EPI_DSIG || EPI == EPI_BIAS_SAMPLE) && WK > 1 && KH_SCHED >= 2) {
     if (vec && p.splitk == 1 && p.a_bytes > 0 && p.K % (kBK * WK) != 0 && (((AK || BK_) ? (p.K & 3) : 0) == 0)) {
       hipLaunchKernelGGL((gemm_kernel<BM, BN, kBK, WK, AK, BK_, EPI, true, true>), dim3(nblk), dim3(256), p.dyn_lds, st, p);
       return;

@@ -1,27 +1,11 @@
-// Per-element HybridTaus generator (three Tausworthe steps xor one LCG step), uniform,
-// Box-Muller gaussian, and the two fused consumers used by RBM CD-1 sampling.
-// Restates src/cudamatrix/cu-randkernels.cu:44-120 so that equal seeds give equal draws.
+// Per-element HybridTaus generator (kh::hybrid_taus, common.h), uniform, Box-Muller gaussian, and the two fused
+// consumers used by RBM CD-1 sampling.  Restates src/cudamatrix/cu-randkernels.cu:44-120 so that equal seeds give
+// equal draws.
 #include "common.h"
 
 namespace {
 
-__device__ __forceinline__ uint32_t taus_step(uint32_t &z, int s1, int s2, int s3, uint32_t m) {
-  const uint32_t b = (((z << s1) ^ z) >> s2);
-  return z = (((z & m) << s3) ^ b);
-}
-__device__ __forceinline__ uint32_t lcg_step(uint32_t &z) { return z = 1664525u * z + 1013904223u; }
-
-// uniform in (0,1): the product is formed in double and rounded to float; values that round
-// to 0 or 1 are rejected and redrawn
-__device__ __forceinline__ float hybrid_taus(uint32_t &z1, uint32_t &z2, uint32_t &z3, uint32_t &z4) {
-  float v;
-  do {
-    const uint32_t bits = taus_step(z1, 13, 19, 12, 4294967294u) ^ taus_step(z2, 2, 25, 4, 4294967288u) ^
-                          taus_step(z3, 3, 11, 17, 4294967280u) ^ lcg_step(z4);
-    v = (float)(2.3283064365387e-10 * (double)bits);
-  } while (!(v > 0.0f && v < 1.0f));
-  return v;
-}
+using kh::hybrid_taus;
 
 __device__ __forceinline__ float box_muller(uint32_t &z1, uint32_t &z2, uint32_t &z3, uint32_t &z4) {
   const float two_pi = 6.283185307179586476925286766558f;

@@ -5,6 +5,7 @@
 #ifndef KALDI_AMD_NNET_NNET_RBM_H_
 #define KALDI_AMD_NNET_NNET_RBM_H_
 #include "cudamatrix/cu-math.h"
+#include "cudamatrix/cu-rand.h"
 #include "nnet/nnet-component.h"
 
 namespace kaldi {
@@ -19,6 +20,11 @@ class RbmBase : public UpdatableComponent {
   /// the same step, which also adds the reconstruction error 1/2 * sum((neg_vis - pos_vis)^2) to a device counter
   virtual void RbmUpdate(const CuMatrix<BaseFloat> &pos_vis, const CuMatrix<BaseFloat> &pos_hid,
                          const CuMatrix<BaseFloat> &neg_vis, const CuMatrix<BaseFloat> &neg_hid, double *mse_loss) = 0;
+  /// Propagate(in, probs) followed by cu_rand->BinarizeProbs(*probs, states) -- the positive phase of a CD-1 step
+  /// with Bernoulli hidden units (nnetbin/rbm-train-cd1-frmshuff.cc:141-146) -- in one launch: same probabilities,
+  /// same states, same generator state afterwards.  Not in the reference.
+  virtual void PropagateSample(const CuMatrix<BaseFloat> &in, CuRand<BaseFloat> *cu_rand, CuMatrix<BaseFloat> *probs,
+                               CuMatrix<BaseFloat> *states) = 0;
   virtual RbmNodeType VisType() const = 0;
   virtual RbmNodeType HidType() const = 0;
   virtual void WriteAsNnet(std::ostream &os, bool binary) const = 0;
@@ -61,6 +67,25 @@ class Rbm : public RbmBase {
     CU_SAFE_CALL(hipF_affine_forward(S(), hid_type_ == BERNOULLI ? KH_ACT_SIGMOID : KH_ACT_NONE, KH_TRANS, in.NumRows(),
                                      output_dim_, input_dim_, in.Data(), in.Stride(), vis_hid_.Data(), vis_hid_.Stride(),
                                      hid_bias_.Data(), out->Data(), out->Stride()));
+  }
+  void PropagateSample(const CuMatrix<BaseFloat> &in, CuRand<BaseFloat> *cu_rand, CuMatrix<BaseFloat> *probs,
+                       CuMatrix<BaseFloat> *states) {
+    KALDI_ASSERT(hid_type_ == BERNOULLI && cu_rand != NULL && probs != states);
+    if (input_dim_ != in.NumCols()) KALDI_ERR << "Nonmatching dims, component:" << input_dim_ << " data:" << in.NumCols();
+    if (output_dim_ != probs->NumCols() || in.NumRows() != probs->NumRows()) probs->Resize(in.NumRows(), output_dim_);
+    if (output_dim_ != states->NumCols() || in.NumRows() != states->NumRows()) states->Resize(in.NumRows(), output_dim_);
+    static const bool two_calls = getenv("KALDI_AMD_UNFUSED_SAMPLING") != NULL;  // for A/B measurements
+    if (two_calls || states->Stride() != probs->Stride()) {
+      PropagateFnc(in, probs);
+      cu_rand->BinarizeProbs(*probs, states);
+      return;
+    }
+    CuProfileScope p("Rbm::PropagateSample");
+    uint32 *z1, *z2, *z3, *z4;
+    cu_rand->States(*probs, &z1, &z2, &z3, &z4);
+    CU_SAFE_CALL(hipF_affine_forward_sample(S(), in.NumRows(), output_dim_, input_dim_, in.Data(), in.Stride(), vis_hid_.Data(),
+                                            vis_hid_.Stride(), hid_bias_.Data(), probs->Data(), probs->Stride(), states->Data(),
+                                            states->Stride(), z1, z2, z3, z4));
   }
   void BackpropagateFnc(const CuMatrix<BaseFloat> &, CuMatrix<BaseFloat> *) {
     KALDI_ERR << "Cannot backpropagate through RBM!"

@@ -102,12 +102,12 @@ int main(int argc, char *argv[]) {
                 << " segments: " << num_done << " frames: " << tot_t << "\n";
       while (!cache.Empty()) {
         cache.GetBunch(&pos_vis, &dummy_targets);
-        // positive phase
-        rbm.Propagate(pos_vis, &pos_hid);
-        // sample the hidden layer to drive the reconstruction
+        // positive phase, and the sample of the hidden layer that drives the reconstruction
         if (rbm.HidType() == Rbm::BERNOULLI) {
-          cu_rand.BinarizeProbs(pos_hid, &neg_hid);
+          // (rbm.Propagate(pos_vis, &pos_hid); cu_rand.BinarizeProbs(pos_hid, &neg_hid); in one launch)
+          rbm.PropagateSample(pos_vis, &cu_rand, &pos_hid, &neg_hid);
         } else {
+          rbm.Propagate(pos_vis, &pos_hid);
           neg_hid.CopyFromMat(pos_hid);
           cu_rand.AddGaussNoise(&neg_hid);
         }

@@ -230,21 +230,31 @@ def test_sharded_exchange_gives_the_bits_of_the_summed_one(hip, nn, tmp_path, mo
     got = {}
     hip.call("hipK_comm_init_loopback", R)
     try:
-        for exchange in ("sum", "shard"):
+        # (the sharded exchange with its layers in one chunk, in the default three, and one layer per chunk)
+        for exchange, chunks in (("sum", None), ("shard", "1"), ("shard", "3"), ("shard", "8")):
             monkeypatch.setenv("KALDI_AMD_DP_EXCHANGE", exchange)
+            if chunks:
+                monkeypatch.setenv("KALDI_AMD_DP_CHUNKS", chunks)
             dp = nn.Trainer(str(model))
             dp.set_train_opts(0.05, 0.7, 1e-4, 0.0, 1.5, True, True)
             dp.set_data_parallel(R)
             for s_ in range(steps):
                 x, t = hip.DevMatrix.from_numpy(X[s_]), hip.DevMatrix.from_numpy(T[s_], pitched=False)
                 dp.train_bunch(x.ptr, x.stride, N, dims[0], t.ptr)
-            got[exchange] = [dp.layer_params(i, dims[i // 2 + 1], dims[i // 2]) for i in (0, 2, 4)]
+            # the written model goes through Nnet::Write, which waits for the exchange of the last step
+            dp.write(str(tmp_path / ("out_%s_%s.nnet" % (exchange, chunks))))
+            got[(exchange, chunks)] = [dp.layer_params(i, dims[i // 2 + 1], dims[i // 2]) for i in (0, 2, 4)]
             dp.close()
     finally:
         hip.call("hipK_comm_destroy")
-    for (Wa, ba), (Wb, bb) in zip(got["sum"], got["shard"]):
-        assert np.array_equal(Wa, Wb) and np.array_equal(ba, bb)
-    assert not np.array_equal(got["sum"][0][0], np.zeros_like(got["sum"][0][0]))
+        monkeypatch.delenv("KALDI_AMD_DP_CHUNKS", raising=False)
+    for key in (("shard", "1"), ("shard", "3"), ("shard", "8")):
+        for (Wa, ba), (Wb, bb) in zip(got[("sum", None)], got[key]):
+            assert np.array_equal(Wa, Wb) and np.array_equal(ba, bb), key
+        written = [l for l in O.read_nnet((tmp_path / ("out_%s_%s.nnet" % key)).read_bytes()) if isinstance(l, O.BiasedLinearity)]
+        for (Wa, ba), l in zip(got[key], written):
+            assert np.array_equal(Wa, l.W) and np.array_equal(ba, l.b), key
+    assert not np.array_equal(got[("sum", None)][0][0], np.zeros_like(got[("sum", None)][0][0]))
 
 
 def test_rccl_entry_points_with_one_rank(nn):

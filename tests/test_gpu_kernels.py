@@ -585,6 +585,39 @@ def test_affine_update_group_equals_single_launches(hip, mom):
         assert np.array_equal(s["Wb"].numpy(), w)
 
 
+@pytest.mark.parametrize("N,O_,I", [(256, 2048, 440), (256, 2048, 2048), (37, 50, 24), (64, 130, 72), (300, 700, 260)])
+def test_affine_forward_sample_equals_two_calls(hip, N, O_, I):
+    """hipF_affine_forward_sample (sigmoid(in * W^T + b) and the Bernoulli sample of it in ONE launch: the positive
+    phase of an RBM CD-1 step) against hipF_affine_forward followed by hipF_binarize_probs_rand on copies of the same
+    generator state: the same probabilities, the same states and the same generator state afterwards, bit for bit,
+    over two consecutive calls; the padding of the state arrays is left alone."""
+    h = hip
+    rs = np.random.RandomState(N + O_)
+    x = h.DevMatrix.from_numpy(rs.randn(N, I).astype(f32))
+    W = h.DevMatrix.from_numpy((0.3 * rs.randn(O_, I)).astype(f32))
+    b = dev(h, (0.2 * rs.randn(O_)).astype(f32), False)
+    pa, sa, pb, sb = (h.DevMatrix(N, O_) for _ in range(4))
+    seeds = [rs.randint(128, 2 ** 31 - 1, (N, O_)).astype(np.uint32) for _ in range(4)]
+    za = [h.DevMatrix.from_numpy(z) for z in seeds]   # pitched like the probabilities: the same index for both
+    zb = [h.DevMatrix.from_numpy(z) for z in seeds]
+    assert za[0].stride == pa.stride
+    for rep in range(2):
+        h.call("hipF_affine_forward", None, h.ACT_SIGMOID, h.TRANS, N, O_, I, x.ptr, x.stride, W.ptr, W.stride, b.ptr, pa.ptr, pa.stride)
+        h.call("hipF_binarize_probs_rand", None, sa.ptr, pa.ptr, za[0].ptr, za[1].ptr, za[2].ptr, za[3].ptr, pa.dim)
+        h.call("hipF_affine_forward_sample", None, N, O_, I, x.ptr, x.stride, W.ptr, W.stride, b.ptr, pb.ptr, pb.stride, sb.ptr, sb.stride,
+               zb[0].ptr, zb[1].ptr, zb[2].ptr, zb[3].ptr)
+        assert np.array_equal(pa.numpy(), pb.numpy()), rep
+        assert np.array_equal(sa.numpy(), sb.numpy()), rep
+        for k in range(4):
+            assert np.array_equal(za[k].numpy(), zb[k].numpy()), (rep, k)
+    states = sb.numpy()
+    assert set(np.unique(states).tolist()) <= {0.0, 1.0}
+    assert abs(states.mean() - pb.numpy().mean()) < 0.02
+    with pytest.raises(h.HipError):
+        h.call("hipF_affine_forward_sample", None, N, O_, I, x.ptr, x.stride, W.ptr, W.stride, b.ptr, pb.ptr, pb.stride, sb.ptr, sb.stride + 4,
+               zb[0].ptr, zb[1].ptr, zb[2].ptr, zb[3].ptr)
+
+
 @pytest.mark.parametrize("width,nl", [(2048, 6), (1024, 3)])
 def test_affine_forward_chain_equals_separate_launches(hip, width, nl):
     """hipF_affine_forward_chain (dependent hidden layers in one launch, activations handed from workgroup to workgroup
