@@ -310,18 +310,49 @@ __global__ __launch_bounds__(kSoftmaxThreads) void softmax_vec_kernel(float *y, 
     row_store4(rsy, (threadIdx.x + k * kSoftmaxThreads) * 4, v[k].x * inv, v[k].y * inv, v[k].z * inv, v[k].w * inv);
 }
 
-// Short rows (cols <= 256 * NV), a matrix of many of them: one WAVE per row, four rows per workgroup.  The row lives
-// in NV float4 per lane (16-byte buffer loads bounded by the row's descriptor, all in flight together), maximum and
-// sum are wave reductions: no LDS, no barrier, a quarter of the workgroups.  Plain softmax only (one slab, no bias).
+// Short rows (cols <= 256 * NV): one WAVE per row, four rows per workgroup.  The row lives in NV float4 per lane
+// (16-byte buffer loads bounded by the row's descriptor, all in flight together: every slab and the bias, summed in
+// slab order and then the bias, as in softmax_row_regs), maximum and sum are wave reductions: no LDS, no barrier.
+// v[] receives exp(x - max) of this lane's columns (0 past the end), the return value is 1 / sum.
 template <int NV>
-__global__ __launch_bounds__(256) void softmax_wave_kernel(float *y, int ldy, const float *x, int ldx, int rows, int cols) {
+__device__ __forceinline__ float softmax_row_wave(float4 (&v)[NV], const float *px, int nslab, size_t slab_stride,
+                                                  const float *bias, int cols) {
   const int lane = threadIdx.x & 63;
-  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (r >= rows) return;
-  const __amdgpu_buffer_rsrc_t rs = row_rsrc(x + (size_t)r * ldx, cols);
-  float4 v[NV];
+  const __amdgpu_buffer_rsrc_t rs0 = row_rsrc(px, cols);
 #pragma unroll
-  for (int k = 0; k < NV; ++k) v[k] = row_load4(rs, (lane + k * 64) * 4);
+  for (int k = 0; k < NV; ++k) v[k] = row_load4(rs0, (lane + k * 64) * 4);
+  float4 b4[NV];
+  if (bias) {
+    const int whole = cols & ~3;  // (the bias vector is not padded: whole groups of 4 by the descriptor, a ragged end by hand)
+    const __amdgpu_buffer_rsrc_t rsb = row_rsrc(bias, whole);
+#pragma unroll
+    for (int k = 0; k < NV; ++k) b4[k] = row_load4(rsb, (lane + k * 64) * 4);
+    if (cols != whole) {
+#pragma unroll
+      for (int k = 0; k < NV; ++k)
+        if ((lane + k * 64) * 4 == whole) {
+          b4[k].x = bias[whole];
+          if (whole + 1 < cols) b4[k].y = bias[whole + 1];
+          if (whole + 2 < cols) b4[k].z = bias[whole + 2];
+        }
+    }
+  }
+  for (int sl = 1; sl < nslab; ++sl) {
+    const __amdgpu_buffer_rsrc_t rs = row_rsrc(px + (size_t)sl * slab_stride, cols);
+    float4 a[NV];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) a[k] = row_load4(rs, (lane + k * 64) * 4);
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      v[k].x += a[k].x; v[k].y += a[k].y; v[k].z += a[k].z; v[k].w += a[k].w;
+    }
+  }
+  if (bias) {
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      v[k].x += b4[k].x; v[k].y += b4[k].y; v[k].z += b4[k].z; v[k].w += b4[k].w;
+    }
+  }
   float mx = -INFINITY;
 #pragma unroll
   for (int k = 0; k < NV; ++k) {
@@ -343,7 +374,16 @@ __global__ __launch_bounds__(256) void softmax_wave_kernel(float *y, int ldy, co
     sum += (v[k].x + v[k].y) + (v[k].z + v[k].w);
   }
   sum = kh::wave_sum(sum);
-  const float inv = 1.0f / sum;
+  return 1.0f / sum;
+}
+template <int NV>
+__global__ __launch_bounds__(256) void softmax_wave_kernel(float *y, int ldy, const float *x, int ldx, int nslab, size_t slab_stride,
+                                                           const float *bias, int rows, int cols) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  float4 v[NV];
+  const float inv = softmax_row_wave<NV>(v, x + (size_t)r * ldx, nslab, slab_stride, bias, cols);
   const __amdgpu_buffer_rsrc_t rsy = row_rsrc(y + (size_t)r * ldy, cols);
 #pragma unroll
   for (int k = 0; k < NV; ++k) row_store4(rsy, (lane + k * 64) * 4, v[k].x * inv, v[k].y * inv, v[k].z * inv, v[k].w * inv);
@@ -820,6 +860,69 @@ __global__ __launch_bounds__(kSoftmaxThreads) void softmax_xent_vec_kernel(float
   if (threadIdx.x == 0) __hip_atomic_store(xf.tail.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// The same for rows of up to 2048 columns (an RM-sized output layer): one wave per row, four rows and ONE arrival per
+// workgroup, no block reduction.  Same order as above -- results and arrival first, row stores behind them -- with
+// the wait for the results counted past the row stores (the memory counter retires in order).  Posteriors, arg-max,
+// target posterior and diff have the bits of softmax_wave_kernel followed by the loss kernels.
+template <int NV>
+__global__ __launch_bounds__(256) void softmax_xent_wave_kernel(float *y, int ldy, const float *x, int ldx, int nslab,
+                                                                size_t slab_stride, const float *bias, int cols, XentFuse xf) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r < xf.rows) {
+    float4 v[NV];
+    const float inv = softmax_row_wave<NV>(v, x + (size_t)r * ldx, nslab, slab_stride, bias, cols);
+    const int t = xf.tgt[r];
+    const bool t_ok = (t >= 0 && t < cols);
+    const __amdgpu_buffer_rsrc_t rsy = row_rsrc(y + (size_t)r * ldy, xf.write_post ? cols : 0);  // 0 columns: nothing is written
+    const __amdgpu_buffer_rsrc_t rsd = row_rsrc(xf.diff + (size_t)r * xf.lddiff, cols);
+    MaxId m;
+    m.v = -1e21f;
+    m.i = -1;
+    float pt = 0.0f;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+#pragma clang fp contract(off)
+      const int c = (lane + k * 64) * 4;
+      const float e[4] = {v[k].x * inv, v[k].y * inv, v[k].z * inv, v[k].w * inv};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const bool in = c + j < cols;
+        const bool up = in && e[j] > m.v;  // ascending columns, strict: the first maximum stays
+        m.v = up ? e[j] : m.v;
+        m.i = up ? c + j : m.i;
+        pt = (in && (c + j == t)) ? e[j] : pt;
+      }
+    }
+    m = wave_best(m);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) pt += __shfl_xor(pt, o, 64);  // the target's posterior lives in one lane
+    if (lane == 0) {
+      const float ptv = t_ok ? pt : 0.0f;
+      row_result_store(xf.log_post, xf.max_id, r, logf(ptv < 1e-20f ? 1e-20f : ptv), m.i);
+    }
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+#pragma clang fp contract(off)
+      const int c = (lane + k * 64) * 4;
+      float e[4] = {v[k].x * inv, v[k].y * inv, v[k].z * inv, v[k].w * inv};
+      row_store4(rsy, c, e[0], e[1], e[2], e[3]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) e[j] = (c + j < cols && c + j == t) ? e[j] - 1.0f : e[j];
+      row_store4(rsd, c, e[0], e[1], e[2], e[3]);
+    }
+    // the two result stores have reached the L2 once all but the 2 * NV row stores behind them have retired
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NV) : "memory");
+  }
+  __shared__ unsigned arrived;
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // (the row stores stay in flight)
+  if (threadIdx.x == 0) arrived = __hip_atomic_fetch_add(xf.tail.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  if (arrived != gridDim.x - 1) return;
+  xent_accum_block(xf.tgt, xf.log_post, xf.max_id, xf.tail.counters, xf.tail.loss, xf.rows);
+  if (threadIdx.x == 0) __hip_atomic_store(xf.tail.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // ---- fused Mse / MseProgress Eval ------------------------------------------------------------
 // One workgroup per row, one launch: kh::mse_row_and_total (a second one-workgroup kernel for the total cost
 // ~2.5-4 us per call on the critical path of an RBM step).
@@ -865,7 +968,14 @@ int softmax_slabs_launch(hipStream_t st, float *y, int ldy, const float *x, int 
       if (!xf.log_post) xf.log_post = (float *)((char *)ws + slabs);
       if (!xf.max_id) xf.max_id = (int32_t *)((char *)ws + slabs + (size_t)rows * 4);
     }
-    if (cols <= 4 * kSoftmaxThreads * 2)
+    if (cols <= 2048) {
+      // short rows: a wave per row (the same choice as the stand-alone softmax below: same posteriors)
+      const dim3 grid((rows + 3) / 4), block(256);
+      if (cols <= 512) hipLaunchKernelGGL((softmax_xent_wave_kernel<2>), grid, block, 0, st, y, ldy, x, ldx, nslab, slab_stride, bias, cols, xf);
+      else if (cols <= 1024) hipLaunchKernelGGL((softmax_xent_wave_kernel<4>), grid, block, 0, st, y, ldy, x, ldx, nslab, slab_stride, bias, cols, xf);
+      else if (cols <= 1536) hipLaunchKernelGGL((softmax_xent_wave_kernel<6>), grid, block, 0, st, y, ldy, x, ldx, nslab, slab_stride, bias, cols, xf);
+      else hipLaunchKernelGGL((softmax_xent_wave_kernel<8>), grid, block, 0, st, y, ldy, x, ldx, nslab, slab_stride, bias, cols, xf);
+    } else if (cols <= 4 * kSoftmaxThreads * 2)
       hipLaunchKernelGGL((softmax_xent_vec_kernel<2>), dim3(rows), dim3(kSoftmaxThreads), 0, st, y, ldy, x, ldx, nslab,
                          slab_stride, bias, cols, xf);
     else if (cols <= 4 * kSoftmaxThreads * 3)
@@ -876,15 +986,21 @@ int softmax_slabs_launch(hipStream_t st, float *y, int ldy, const float *x, int 
                          slab_stride, bias, cols, xf);
     return kh::launch_status();
   }
-  // Plain softmax of short rows: one wave per row.  Chosen by the row LENGTH only, so that a row's bits do not depend
-  // on how many rows share the call.
-  if (vec && !xent && nslab == 1 && !bias && cols <= 2048) {
+  // Short rows: one wave per row.  Chosen by the row LENGTH only, so that a row's bits do not depend on how many
+  // rows share the call.
+  if (vec && cols <= 2048) {
     const dim3 grid((rows + 3) / 4), block(256);
-    if (cols <= 512) hipLaunchKernelGGL((softmax_wave_kernel<2>), grid, block, 0, st, y, ldy, x, ldx, rows, cols);
-    else if (cols <= 1024) hipLaunchKernelGGL((softmax_wave_kernel<4>), grid, block, 0, st, y, ldy, x, ldx, rows, cols);
-    else if (cols <= 1536) hipLaunchKernelGGL((softmax_wave_kernel<6>), grid, block, 0, st, y, ldy, x, ldx, rows, cols);
-    else hipLaunchKernelGGL((softmax_wave_kernel<8>), grid, block, 0, st, y, ldy, x, ldx, rows, cols);
-    return kh::launch_status();
+    if (cols <= 512) hipLaunchKernelGGL((softmax_wave_kernel<2>), grid, block, 0, st, y, ldy, x, ldx, nslab, slab_stride, bias, rows, cols);
+    else if (cols <= 1024) hipLaunchKernelGGL((softmax_wave_kernel<4>), grid, block, 0, st, y, ldy, x, ldx, nslab, slab_stride, bias, rows, cols);
+    else if (cols <= 1536) hipLaunchKernelGGL((softmax_wave_kernel<6>), grid, block, 0, st, y, ldy, x, ldx, nslab, slab_stride, bias, rows, cols);
+    else hipLaunchKernelGGL((softmax_wave_kernel<8>), grid, block, 0, st, y, ldy, x, ldx, nslab, slab_stride, bias, rows, cols);
+    int rc = kh::launch_status();
+    if (rc != KH_OK || !xent) return rc;
+    // (a fused request whose shape the fused kernel did not take: the loss as a second kernel)
+    MatrixDim d = {rows, cols, ldy};
+    if (xent->lddiff != ldy) return KH_ERR_INVALID_ARG;
+    return hipF_xent_eval((khStream_t)st, y, xent->tgt, xent->diff, xent->log_post, xent->max_id, xent->counters,
+                          xent->loss, d);
   }
   if (vec && cols <= 4 * kSoftmaxThreads * 2)
     hipLaunchKernelGGL((softmax_vec_kernel<2>), dim3(rows), dim3(kSoftmaxThreads), 0, st, y, ldy, x, ldx, nslab,
