@@ -373,6 +373,10 @@ typedef struct {
   float *gb;
 } khAffineGradient;
 int hipF_affine_gradient_group(khStream_t s, int32_t count, const khAffineGradient *items);
+/* The same, and `done` (an event of hipK_event_create_ordering; may be NULL) is recorded behind the call's work: bound
+ * to the call's last launch as that launch's own completion signal where possible, so that the stream's queue holds
+ * no separate mark for the next launch to wait behind. */
+int hipF_affine_gradient_group_marked(khStream_t s, int32_t count, const khAffineGradient *items, khEvent_t done);
 
 /* The two halves of hipF_affine_update on their own, so that a caller can queue them on different
  * streams (the bias half reads only e; the weight half reads only e and in besides W):

@@ -938,6 +938,10 @@ KH_EXPORT int hipF_affine_update_group(khStream_t s, int32_t count, const khAffi
 }
 
 KH_EXPORT int hipF_affine_gradient_group(khStream_t s, int32_t count, const khAffineGradient *items) {
+  return hipF_affine_gradient_group_marked(s, count, items, nullptr);
+}
+
+KH_EXPORT int hipF_affine_gradient_group_marked(khStream_t s, int32_t count, const khAffineGradient *items, khEvent_t done) {
   KH_CHECK_INIT();
   KH_REQUIRE(count >= 0 && (count == 0 || items != nullptr));
   hipStream_t st = kh::pick(s);
@@ -958,11 +962,13 @@ KH_EXPORT int hipF_affine_gradient_group(khStream_t s, int32_t count, const khAf
   GemmGroup g;
   memset(&g, 0, sizeof(g));
   double flops = 0.0;
-  auto flush = [&]() -> int {
+  bool marked = false;  // `done` has been bound to a launch (only ever the call's last one)
+  auto flush = [&](bool last) -> int {
     if (g.n == 0) return KH_OK;
     {
       TimedLaunch tl(st, flops);
-      launch_grad_group(st, g, big);
+      launch_grad_group(st, g, big, (last && !timing().enabled) ? (hipEvent_t)done : nullptr);
+      marked = last && !timing().enabled && done != nullptr;
     }
     g.n = 0;
     g.first[0] = 0;
@@ -982,7 +988,7 @@ KH_EXPORT int hipF_affine_gradient_group(khStream_t s, int32_t count, const khAf
     apply_plan(p, plan, false, false);
     p.n_fastest = p.tiles_m > 2 * p.tiles_n ? 1 : 0;
     if (!vec || !cvec || p.a_bytes == 0 || force_bm > 0) {
-      int rc = flush();
+      int rc = flush(false);
       if (rc != KH_OK) return rc;
       rc = hipF_gemm(s, KH_TRANS, KH_NO_TRANS, u.O, u.I, u.N, 1.0f, u.e, u.lde, u.in, u.ldin, 0.0f, u.gW, u.ldg);
       if (rc != KH_OK) return rc;
@@ -996,11 +1002,15 @@ KH_EXPORT int hipF_affine_gradient_group(khStream_t s, int32_t count, const khAf
     g.first[g.n + 1] = g.first[g.n] + ((blocks + 7) & ~7);
     flops += 2.0 * p.M * p.N * p.K;
     if (++g.n == kMaxGroup) {
-      const int rc = flush();
+      const int rc = flush(i == count - 1);
       if (rc != KH_OK) return rc;
     }
   }
-  return flush();
+  const int rc = flush(true);
+  if (rc != KH_OK) return rc;
+  // (nothing left for the last launch to carry the mark, or launches bracketed by timing events: a mark of its own)
+  if (done != nullptr && !marked) KH_HIP(hipEventRecord((hipEvent_t)done, st));
+  return KH_OK;
 }
 
 KH_EXPORT int hipF_affine_update_bias(khStream_t s, int32_t N, int32_t O, const float *e, int32_t lde, float gscale,

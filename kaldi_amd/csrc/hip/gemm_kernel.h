@@ -99,7 +99,8 @@ struct GemmGroup {
   GemmParams p[kMaxGroup];
 };
 void launch_update_group(hipStream_t st, const GemmGroup &g, bool big);  // big: 128 x 128 tiles, else 64 x 64
-void launch_grad_group(hipStream_t st, const GemmGroup &g, bool big);    // the same launch with the EPI_GRAD epilogue
+// the same launch with the EPI_GRAD epilogue; `done` (may be null) is an event bound to the launch's own completion
+void launch_grad_group(hipStream_t st, const GemmGroup &g, bool big, hipEvent_t done);
 
 // Dependent forward products in one launch (gemm_chain_kernel below).
 constexpr int kMaxChain = 8;
@@ -120,6 +121,7 @@ template <int EPI>
 void launch_reduce(hipStream_t st, const GemmParams &p, const float *slabs, int ld_slab);
 
 #ifdef KHG_DEFINE_KERNELS
+#include <hip/hip_ext.h>
 
 #ifdef KH_GEMM_STAMPS
 // diagnostic build only: cycle stamps of wave 0 of every workgroup, 16 slots per workgroup
@@ -1413,9 +1415,12 @@ __global__ __launch_bounds__(BIG ? 512 : 256) __attribute__((amdgpu_waves_per_eu
   update_tile<BT, BT, kBK, 1, false, false, EPI_GRAD, true, BIG ? 8 : 4>(p, lds, bid, ntiles);
 }
 
-void launch_grad_group(hipStream_t st, const GemmGroup &g, bool big) {
-  if (big) hipLaunchKernelGGL(gemm_grad_group_kernel<true>, dim3(g.first[g.n]), dim3(512), 0, st, g);
-  else hipLaunchKernelGGL(gemm_grad_group_kernel<false>, dim3(g.first[g.n]), dim3(256), 0, st, g);
+void launch_grad_group(hipStream_t st, const GemmGroup &g, bool big, hipEvent_t done) {
+  // An event recorded behind the launch is a packet of its own in the stream's queue, and the launch after it waits
+  // ~6 us for it (kernel trace of the data-parallel step); bound to the launch itself (hipExtLaunchKernelGGL's stop
+  // event) the event is the kernel's own completion signal and the queue holds nothing extra.
+  if (big) hipExtLaunchKernelGGL(gemm_grad_group_kernel<true>, dim3(g.first[g.n]), dim3(512), 0, st, nullptr, done, 0, g);
+  else hipExtLaunchKernelGGL(gemm_grad_group_kernel<false>, dim3(g.first[g.n]), dim3(256), 0, st, nullptr, done, 0, g);
 }
 #endif  // KHG_DEFINE_GRAD_GROUP
 

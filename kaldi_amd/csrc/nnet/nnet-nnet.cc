@@ -220,9 +220,9 @@ void Nnet::Backpropagate(const CuMatrix<BaseFloat> &in_err, CuMatrix<BaseFloat> 
       // back by ~6 us (kernel trace).
       if (i == ch.layers.back() && &ch == &dp_chunks_[0]) {
         CuProfileScope p("BiasedLinearity::ComputeGradient");
-        CU_SAFE_CALL(hipF_affine_gradient_group(dev.MainStream(), static_cast<int32>(dp_grad_items_.size()), &dp_grad_items_[0]));
+        CU_SAFE_CALL(hipF_affine_gradient_group_marked(dev.MainStream(), static_cast<int32>(dp_grad_items_.size()), &dp_grad_items_[0],
+                                                       ch.grad_ready));
         dp_grad_items_.clear();
-        CU_SAFE_CALL(hipK_event_record(ch.grad_ready, dev.MainStream()));
       }
       return;
     }
@@ -402,10 +402,10 @@ void Nnet::Backpropagate(const CuMatrix<BaseFloat> &in_err, CuMatrix<BaseFloat> 
       } else {
         {
           CuProfileScope p("BiasedLinearity::ComputeGradient");
-          CU_SAFE_CALL(hipF_affine_gradient_group(dev.MainStream(), static_cast<int32>(dp_grad_items_.size()), &dp_grad_items_[0]));
+          CU_SAFE_CALL(hipF_affine_gradient_group_marked(dev.MainStream(), static_cast<int32>(dp_grad_items_.size()),
+                                                         &dp_grad_items_[0], ch.grad_ready));
           dp_grad_items_.clear();
         }
-        CU_SAFE_CALL(hipK_event_record(ch.grad_ready, dev.MainStream()));
         CU_SAFE_CALL(hipK_stream_wait_event(xs, ch.grad_ready));
         CU_SAFE_CALL(hipF_reduce_scatter_sum(xs, dp_g_arena_ + ch.begin, per_rank));
       }
