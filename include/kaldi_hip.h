@@ -508,6 +508,16 @@ int hipK_comm_init_loopback(int nranks);
  * names, only that rank's shard, the all-gather brings nothing in -- the device work of one real rank without the
  * link traffic.  The other shards of the weights are then never stepped: the numbers of such a run mean nothing. */
 int hipK_comm_init_loopback_one_rank(int nranks);
+/* Real ranks WITHOUT RCCL, for validation on a box whose ranks must share one GPU (RCCL wants a device per rank):
+ * the processes exchange through the file `path`, which all of them map -- a counting barrier and one slot of
+ * slot_bytes (a multiple of 256, at least 4096) per rank.  Every collective below then copies device -> slot,
+ * meets the other ranks, combines the slots on the host in rank order (all ranks get the same bits; a
+ * reduce-scatter gives the bits of the all-reduce) and copies back; buffers larger than a slot go in pieces.
+ * Blocking and slow: a test vehicle for the multi-rank code paths with different data on every rank, not a
+ * transport.  `path` must not exist before the job (a new file reads as zeros, the barrier's start state) and
+ * should live in memory (/dev/shm); a rank that waits two minutes for the others fails with KH_ERR_COMM, and so
+ * does every later call on that file. */
+int hipK_comm_init_host(const char *path, int rank, int nranks, size_t slot_bytes);
 int hipK_comm_destroy(void);
 int hipK_comm_rank(int *rank, int *nranks);
 /* in-place sum all-reduce of count floats on stream s (ordered with the kernels on s) */

@@ -2,17 +2,71 @@
 // counterpart (single GPU, src/cudamatrix/cu-device.cc); synchronous data-parallel training
 // sums per-layer gradients with these calls, ordered on the same stream as the kernels.
 #include <rccl/rccl.h>
+#include <fcntl.h>
+#include <sched.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <time.h>
+#include <unistd.h>
+
+#include <atomic>
+#include <vector>
 
 #include "common.h"
 
 namespace {
+// ---- host-staged communicator ----------------------------------------------------------------
+// Real ranks without RCCL: processes (which may share one GPU) exchange through a file that all of them map -- a
+// control block with a counting barrier, then one slot per rank.  A collective copies the rank's data to its slot
+// (device -> host, behind everything queued on the stream), meets the others at the barrier, combines the slots on
+// the host IN RANK ORDER (so every rank computes the same bits, and a reduce-scatter gives the bits of an
+// all-reduce), meets them again and copies the result back.  Blocking and slow by design: it exists so that the
+// multi-rank code paths -- rank-dependent shard offsets, in-place reduce-scatter and all-gather, uneven data -- run
+// with different data on every rank on a box with one GPU.
+struct HostCtl {
+  std::atomic<unsigned> count, generation, failed;
+};
+struct HostComm {
+  int rank = 0, nranks = 1;
+  char *base = nullptr;
+  size_t map_bytes = 0, slot_bytes = 0;
+  static constexpr size_t kCtlBytes = 4096;
+  HostCtl *ctl() { return reinterpret_cast<HostCtl *>(base); }
+  char *slot(int r) { return base + kCtlBytes + (size_t)r * slot_bytes; }
+  // false after two minutes without the others (a rank died): the caller reports an error instead of hanging
+  bool barrier() {
+    HostCtl *c = ctl();
+    if (c->failed.load()) return false;
+    const unsigned g = c->generation.load();
+    if (c->count.fetch_add(1) + 1 == (unsigned)nranks) {
+      c->count.store(0);
+      c->generation.store(g + 1);
+      return true;
+    }
+    const time_t t0 = time(nullptr);
+    while (c->generation.load() == g) {
+      sched_yield();
+      if (c->failed.load() || time(nullptr) - t0 > 120) {
+        c->failed.store(1);
+        return false;
+      }
+    }
+    return true;
+  }
+  void unmap() {
+    if (base) munmap(base, map_bytes);
+    base = nullptr;
+  }
+};
+
 struct Comm {
   ncclComm_t comm = nullptr;
   int rank = 0, nranks = 1;
   bool loopback = false;  // stand-in for nranks replicas that all hold this process's data
   bool one_rank = false;  // ... that does the device work of rank 0 only (timing runs)
+  HostComm *host = nullptr;  // ranks that exchange through a mapped file instead of RCCL
 };
 template <typename T>
 __global__ void scale_kernel(T *buf, size_t n, T f) {
@@ -31,6 +85,107 @@ bool force_rccl() {
 int nccl_fail(ncclResult_t r, const char *what) {
   snprintf(kh::ctx().last_msg, sizeof(kh::ctx().last_msg), "%s: %s", what, ncclGetErrorString(r));
   return KH_ERR_COMM;
+}
+int host_fail(const char *what) {
+  snprintf(kh::ctx().last_msg, sizeof(kh::ctx().last_msg), "host communicator: %s", what);
+  return KH_ERR_COMM;
+}
+
+#define KH_HOST_MEET(h)                                                                  \
+  do {                                                                                   \
+    if (!(h)->barrier()) return host_fail("a rank did not reach the collective (timed out or failed)"); \
+  } while (0)
+
+struct OpSum {
+  template <typename T>
+  static T apply(T a, T b) { return a + b; }
+};
+struct OpMin {
+  template <typename T>
+  static T apply(T a, T b) { return b < a ? b : a; }
+};
+struct OpMax {
+  template <typename T>
+  static T apply(T a, T b) { return b > a ? b : a; }
+};
+
+// pieces[k] of n elements each, device -> this rank's slot (piece k at k * n), all behind the stream's queued work
+template <typename T>
+int host_stage_out(HostComm *h, hipStream_t st, const T *const *pieces, int npieces, size_t n) {
+  T *mine = reinterpret_cast<T *>(h->slot(h->rank));
+  for (int k = 0; k < npieces; ++k)
+    KH_HIP(hipMemcpyAsync(mine + (size_t)k * n, pieces[k], n * sizeof(T), hipMemcpyDeviceToHost, st));
+  KH_HIP(hipStreamSynchronize(st));
+  return KH_OK;
+}
+
+// all-reduce of buf[0..count) in slot-sized chunks
+template <typename T, typename Op>
+int host_allreduce(HostComm *h, hipStream_t st, T *buf, size_t count) {
+  const size_t cap = h->slot_bytes / sizeof(T);
+  std::vector<T> acc;
+  for (size_t off = 0; off < count; off += cap) {
+    const size_t n = count - off < cap ? count - off : cap;
+    const T *piece = buf + off;
+    int rc = host_stage_out(h, st, &piece, 1, n);
+    if (rc != KH_OK) return rc;
+    KH_HOST_MEET(h);
+    acc.assign(reinterpret_cast<const T *>(h->slot(0)), reinterpret_cast<const T *>(h->slot(0)) + n);
+    for (int r = 1; r < h->nranks; ++r) {
+      const T *o = reinterpret_cast<const T *>(h->slot(r));
+      for (size_t i = 0; i < n; ++i) acc[i] = Op::apply(acc[i], o[i]);
+    }
+    KH_HOST_MEET(h);  // every rank has read the slots before anyone refills its own
+    KH_HIP(hipMemcpyAsync(buf + off, acc.data(), n * sizeof(T), hipMemcpyHostToDevice, st));
+    KH_HIP(hipStreamSynchronize(st));
+  }
+  return KH_OK;
+}
+
+// in-place reduce-scatter: this rank's shard of buf becomes the rank-ordered sum of every rank's copy of that shard;
+// the other shards keep this rank's own values, as with RCCL's in-place form
+int host_reduce_scatter(HostComm *h, hipStream_t st, float *buf, size_t shard_count) {
+  const size_t cap = h->slot_bytes / sizeof(float) / h->nranks;
+  if (cap == 0) return host_fail("slot too small for a reduce-scatter over this many ranks");
+  std::vector<float> acc;
+  std::vector<const float *> pieces(h->nranks);
+  for (size_t off = 0; off < shard_count; off += cap) {
+    const size_t n = shard_count - off < cap ? shard_count - off : cap;
+    for (int r = 0; r < h->nranks; ++r) pieces[r] = buf + (size_t)r * shard_count + off;
+    int rc = host_stage_out(h, st, pieces.data(), h->nranks, n);
+    if (rc != KH_OK) return rc;
+    KH_HOST_MEET(h);
+    const size_t mine = (size_t)h->rank * n;
+    acc.assign(reinterpret_cast<const float *>(h->slot(0)) + mine, reinterpret_cast<const float *>(h->slot(0)) + mine + n);
+    for (int r = 1; r < h->nranks; ++r) {
+      const float *o = reinterpret_cast<const float *>(h->slot(r)) + mine;
+      for (size_t i = 0; i < n; ++i) acc[i] += o[i];
+    }
+    KH_HOST_MEET(h);
+    KH_HIP(hipMemcpyAsync(buf + (size_t)h->rank * shard_count + off, acc.data(), n * sizeof(float), hipMemcpyHostToDevice, st));
+    KH_HIP(hipStreamSynchronize(st));
+  }
+  return KH_OK;
+}
+
+// all-gather: rank r's `count` elements at send land at recv + r * count on every rank
+int host_allgather(HostComm *h, hipStream_t st, const float *send, float *recv, size_t count) {
+  const size_t cap = h->slot_bytes / sizeof(float);
+  for (size_t off = 0; off < count; off += cap) {
+    const size_t n = count - off < cap ? count - off : cap;
+    const float *piece = send + off;
+    int rc = host_stage_out(h, st, &piece, 1, n);
+    if (rc != KH_OK) return rc;
+    KH_HOST_MEET(h);
+    for (int r = 0; r < h->nranks; ++r) {
+      float *dst = recv + (size_t)r * count + off;
+      if (r == h->rank && dst == send + off) continue;
+      KH_HIP(hipMemcpyAsync(dst, h->slot(r), n * sizeof(float), hipMemcpyHostToDevice, st));
+    }
+    KH_HIP(hipStreamSynchronize(st));
+    KH_HOST_MEET(h);
+  }
+  return KH_OK;
 }
 }  // namespace
 
@@ -53,11 +208,9 @@ KH_EXPORT int hipK_comm_get_unique_id(unsigned char id[KH_COMM_ID_BYTES]) {
 KH_EXPORT int hipK_comm_init(const unsigned char id[KH_COMM_ID_BYTES], int rank, int nranks) {
   KH_CHECK_INIT();
   KH_REQUIRE(id != nullptr && nranks >= 1 && rank >= 0 && rank < nranks);
+  int rc = hipK_comm_destroy();
+  if (rc != KH_OK) return rc;
   Comm &c = comm();
-  if (c.comm) {
-    KH_NCCL(ncclCommDestroy(c.comm));
-    c.comm = nullptr;
-  }
   ncclUniqueId uid;
   memcpy(&uid, id, KH_COMM_ID_BYTES);
   KH_NCCL(ncclCommInitRank(&c.comm, nranks, uid, rank));
@@ -65,6 +218,35 @@ KH_EXPORT int hipK_comm_init(const unsigned char id[KH_COMM_ID_BYTES], int rank,
   c.nranks = nranks;
   c.loopback = false;
   c.one_rank = false;
+  return KH_OK;
+}
+
+KH_EXPORT int hipK_comm_init_host(const char *path, int rank, int nranks, size_t slot_bytes) {
+  KH_CHECK_INIT();
+  KH_REQUIRE(path != nullptr && nranks >= 1 && rank >= 0 && rank < nranks && slot_bytes >= 4096 && slot_bytes % 256 == 0);
+  int rc = hipK_comm_destroy();
+  if (rc != KH_OK) return rc;
+  const int fd = open(path, O_RDWR | O_CREAT, 0600);
+  if (fd < 0) return host_fail("cannot open the exchange file");
+  HostComm *h = new HostComm;
+  h->rank = rank;
+  h->nranks = nranks;
+  h->slot_bytes = slot_bytes;
+  h->map_bytes = HostComm::kCtlBytes + (size_t)nranks * slot_bytes;
+  // every rank sizes the file to the same length; bytes the file gains read as zero, which is the barrier's start state
+  void *m = ftruncate(fd, (off_t)h->map_bytes) == 0 ? mmap(nullptr, h->map_bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0)
+                                                    : MAP_FAILED;
+  close(fd);
+  if (m == MAP_FAILED) {
+    delete h;
+    return host_fail("cannot size or map the exchange file");
+  }
+  h->base = static_cast<char *>(m);
+  Comm &c = comm();
+  c.host = h;
+  c.rank = rank;
+  c.nranks = nranks;
+  KH_HOST_MEET(h);  // all ranks have joined
   return KH_OK;
 }
 
@@ -93,6 +275,11 @@ KH_EXPORT int hipK_comm_destroy(void) {
     KH_NCCL(ncclCommDestroy(c.comm));
     c.comm = nullptr;
   }
+  if (c.host) {
+    c.host->unmap();
+    delete c.host;
+    c.host = nullptr;
+  }
   c.rank = 0;
   c.nranks = 1;
   c.loopback = false;
@@ -120,6 +307,10 @@ static int allreduce(khStream_t s, T *buf, size_t count, ncclDataType_t dt, nccl
                          (T)c.nranks);
     return kh::launch_status();
   }
+  if (c.host)
+    return op == ncclSum   ? host_allreduce<T, OpSum>(c.host, kh::pick(s), buf, count)
+           : op == ncclMin ? host_allreduce<T, OpMin>(c.host, kh::pick(s), buf, count)
+                           : host_allreduce<T, OpMax>(c.host, kh::pick(s), buf, count);
   if (!c.comm) return KH_ERR_NOT_INITIALISED;
   KH_NCCL(ncclAllReduce(buf, buf, count, dt, op, c.comm, kh::pick(s)));
   return KH_OK;
@@ -142,6 +333,7 @@ KH_EXPORT int hipF_allgather(khStream_t s, const float *send, float *recv, size_
         KH_HIP(hipMemcpyAsync(recv + (size_t)r * count, send, count * sizeof(float), hipMemcpyDeviceToDevice, st));
     return KH_OK;
   }
+  if (c.host) return host_allgather(c.host, st, send, recv, count);
   if (!c.comm) return KH_ERR_NOT_INITIALISED;
   KH_NCCL(ncclAllGather(send, recv, count, ncclFloat32, c.comm, st));
   return KH_OK;
@@ -184,6 +376,7 @@ KH_EXPORT int hipF_reduce_scatter_sum(khStream_t s, float *buf, size_t shard_cou
                        (float)c.nranks);
     return kh::launch_status();
   }
+  if (c.host) return host_reduce_scatter(c.host, kh::pick(s), buf, shard_count);
   if (!c.comm) return KH_ERR_NOT_INITIALISED;
   // in place: the receive buffer is this rank's shard of the send buffer
   KH_NCCL(ncclReduceScatter(buf, buf + (size_t)c.rank * shard_count, shard_count, ncclFloat32, ncclSum, c.comm, kh::pick(s)));
@@ -196,6 +389,7 @@ KH_EXPORT int hipF_allgather_shards(khStream_t s, float *buf, size_t shard_count
   KH_REQUIRE(buf != nullptr);
   Comm &c = comm();
   if (c.loopback || (c.nranks == 1 && !(force_rccl() && c.comm))) return KH_OK;  // every shard is already here
+  if (c.host) return host_allgather(c.host, kh::pick(s), buf + (size_t)c.rank * shard_count, buf, shard_count);
   if (!c.comm) return KH_ERR_NOT_INITIALISED;
   KH_NCCL(ncclAllGather(buf + (size_t)c.rank * shard_count, buf, shard_count, ncclFloat32, c.comm, kh::pick(s)));
   return KH_OK;
@@ -217,6 +411,12 @@ KH_EXPORT int hipK_comm_barrier(khStream_t s) {
   KH_CHECK_INIT();
   Comm &c = comm();
   if (c.nranks == 1 || c.loopback) return hipK_stream_synchronize(s);
+  if (c.host) {
+    int rc = hipK_stream_synchronize(s);
+    if (rc != KH_OK) return rc;
+    KH_HOST_MEET(c.host);
+    return KH_OK;
+  }
   if (!c.comm) return KH_ERR_NOT_INITIALISED;
   void *ws;
   int rc = kh::ensure_workspace(kh::pick(s), 256, &ws);

@@ -108,6 +108,12 @@ inline void DistInit(const DistOptions &o, bool need_comm = true) {
     CU_SAFE_CALL(hipK_comm_init_loopback(o.num_ranks));
     return;
   }
+  if (const char *file = getenv("KALDI_AMD_COMM_HOST_FILE")) {
+    // validation on a box whose ranks share one GPU: real ranks with their own data that exchange through a
+    // mapped file instead of RCCL (blocking, host-staged).  The file must be new for every job.
+    CU_SAFE_CALL(hipK_comm_init_host(file, o.rank, o.num_ranks, size_t(16) << 20));
+    return;
+  }
   unsigned char id[KH_COMM_ID_BYTES];
   const std::string nonce = CommNonce();
   if (o.rank == 0) {

@@ -363,3 +363,123 @@ def test_forward_sharded_over_eight_ranks_swbd_shape_equals_single(hip, nn, tmp_
     # one oracle check on top of the bit-equality: a short utterance's posteriors
     i = int(np.argmin(lens))
     np.testing.assert_allclose(single[utts[i][0]], O.Nnet(layers).feedforward(utts[i][1]), rtol=1e-4, atol=1e-9)
+
+
+def _run_host_ranks(tmp_path, tag, model, data, R, env_extra):
+    """R processes of tests/dp_host_rank.py on GPU 0 over one fresh exchange file -> [params of rank r]"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    xfile = "/dev/shm/kaldi_amd_test_%d_%s" % (os.getpid(), tag)
+    if os.path.exists(xfile):
+        os.unlink(xfile)
+    env = dict(os.environ, **env_extra)
+    try:
+        procs = [subprocess.Popen([sys.executable, os.path.join(root, "tests", "dp_host_rank.py"), str(model), str(data), str(r),
+                                   str(R), xfile, str(tmp_path / ("%s_r%d.npz" % (tag, r)))],
+                                  stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env) for r in range(R)]
+        for p in procs:
+            out, err = p.communicate(timeout=110)
+            assert p.returncode == 0, err.decode()[-3000:]
+    finally:
+        if os.path.exists(xfile):
+            os.unlink(xfile)
+    return [dict(np.load(tmp_path / ("%s_r%d.npz" % (tag, r)))) for r in range(R)]
+
+
+@pytest.mark.parametrize("R", [2, 3])
+def test_real_ranks_with_their_own_rows_train_like_one_process_on_all_rows(hip, nn, tmp_path, R):
+    """R rank PROCESSES on this GPU, each with its own third / half of every bunch, joined by the host-staged
+    communicator (real reduce-scatter / all-gather / all-reduce semantics: rank-dependent shard offsets, in-place
+    buffers, pieces smaller than a layer).  After three steps with momentum, weight decay and the row-norm bound:
+    every rank holds the same bits; the sharded exchange (1 and 3 chunks) gives the bits of the summed one; and
+    the result equals one process trained on the whole bunches, and the numpy oracle, to rounding."""
+    rs = np.random.RandomState(123 + R)
+    dims = [40, 96, 64, 50, 33]
+    data, layers = _model_bytes(rs, dims)
+    model = tmp_path / "m.nnet"
+    model.write_bytes(data)
+    per, steps = 32, 3
+    N = per * R
+    X = rs.standard_normal((steps, N, dims[0])).astype(f32)
+    T = rs.randint(0, dims[-1], (steps, N)).astype(np.int32)
+    opts = np.array([0.05, 0.7, 1e-4, 0.0, 1.5], f32)
+    np.savez(tmp_path / "d.npz", X=X, T=T, split=np.arange(R + 1) * per, opts=opts, dims=np.array(dims))
+    got = {}
+    for exchange, chunks in (("sum", "3"), ("shard", "1"), ("shard", "3")):
+        tag = "%s%s" % (exchange, chunks)
+        got[tag] = _run_host_ranks(tmp_path, tag, model, tmp_path / "d.npz", R,
+                                   {"KALDI_AMD_DP_EXCHANGE": exchange, "KALDI_AMD_DP_CHUNKS": chunks})
+        for r in range(1, R):
+            for k in got[tag][0]:
+                assert np.array_equal(got[tag][0][k], got[tag][r][k]), (tag, r, k)      # replicas stay identical
+        written = [l for l in O.read_nnet((tmp_path / (tag + "_r0.npz.nnet")).read_bytes()) if isinstance(l, O.BiasedLinearity)]
+        for k, l in enumerate(written):
+            assert np.array_equal(l.W, got[tag][0]["W%d" % k]) and np.array_equal(l.b, got[tag][0]["b%d" % k])
+    for tag in ("shard1", "shard3"):
+        for k in got["sum3"][0]:
+            assert np.array_equal(got["sum3"][0][k], got[tag][0][k]), (tag, k)
+    # one process on the whole bunches
+    one = nn.Trainer(str(model))
+    one.set_train_opts(*[float(v) for v in opts], True, True)
+    net = O.Nnet(layers)
+    net.set_train_opts(float(opts[0]), momentum=float(opts[1]), l2_penalty=float(opts[2]), l2_upper_bound=float(opts[4]), average_grad=True)
+    xent = O.Xent()
+    for s in range(steps):
+        x, t = hip.DevMatrix.from_numpy(X[s]), hip.DevMatrix.from_numpy(T[s], pitched=False)
+        one.train_bunch(x.ptr, x.stride, N, dims[0], t.ptr)
+        diff, _, _, _ = xent.eval_vec(net.propagate(X[s]), T[s])
+        net.backpropagate(diff)
+    for k in range(len(dims) - 1):
+        W1, b1 = one.layer_params(2 * k, dims[k + 1], dims[k])
+        for ref_W, ref_b in ((W1, b1), (net.layers[2 * k].W, net.layers[2 * k].b)):
+            np.testing.assert_allclose(got["shard3"][0]["W%d" % k], ref_W, rtol=1e-4, atol=2e-6)
+            np.testing.assert_allclose(got["shard3"][0]["b%d" % k], ref_b, rtol=1e-4, atol=2e-6)
+        assert not np.array_equal(W1, layers[2 * k].W)
+    one.close()
+
+
+def test_two_rank_training_job_on_one_gpu_shard_equals_sum(hip, nn, tmp_path):
+    """nnet-train-xent-hardlab-frmshuff as a real 2-rank job (two processes, each reading its own utterances, joined
+    by the host-staged communicator, KALDI_AMD_COMM_HOST_FILE): the job finishes although the shards are uneven,
+    rank 0's report counts the frames of both ranks, and the model written with the sharded exchange has the bits
+    of the one written with the summed exchange -- and differs from the input model."""
+    rs = np.random.RandomState(19)
+    dims = [20, 48, 32, 9]
+    data, layers = _model_bytes(rs, dims)
+    (tmp_path / "m.nnet").write_bytes(data)
+    lens = [200, 90, 75, 130, 40, 61]
+    utts = [("u%02d" % i, rs.standard_normal((n, dims[0])).astype(f32)) for i, n in enumerate(lens)]
+    alis = [(k, rs.randint(0, dims[-1], m.shape[0]).astype(np.int32)) for k, m in utts]
+    (tmp_path / "f.ark").write_bytes(O.write_matrix_ark(utts))
+    (tmp_path / "a.ark").write_bytes(O.write_int32_vector_ark(alis))
+    want = nn.shard_assign(2, lens)
+    frames = [sum(n for n, w in zip(lens, want) if w == r) for r in range(2)]
+    exe = os.path.join(nn.BIN_DIR, "nnet-train-xent-hardlab-frmshuff")
+    models = {}
+    for exchange in ("sum", "shard"):
+        xfile = "/dev/shm/kaldi_amd_test_%d_job_%s" % (os.getpid(), exchange)
+        if os.path.exists(xfile):
+            os.unlink(xfile)
+        env = dict(os.environ, KALDI_AMD_COMM_HOST_FILE=xfile, KALDI_AMD_DP_EXCHANGE=exchange)
+        try:
+            procs = [subprocess.Popen([exe, "--num-ranks=2", "--rank=%d" % r, "--gpu-id=0", "--bunchsize=32", "--cachesize=128",
+                                       "--learn-rate=0.02", "--momentum=0.5", "ark:" + str(tmp_path / "f.ark"),
+                                       "ark:" + str(tmp_path / "a.ark"), str(tmp_path / "m.nnet"),
+                                       str(tmp_path / ("out_%s_%d.nnet" % (exchange, r)))],
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env) for r in range(2)]
+            logs = []
+            for p in procs:
+                _, err = p.communicate(timeout=110)
+                assert p.returncode == 0, err.decode()[-3000:]
+                logs.append(err.decode())
+        finally:
+            if os.path.exists(xfile):
+                os.unlink(xfile)
+        m = re.search(r"Xent:(\S+) frames:(\d+) err/frm:(\S+)\nFRAME_ACCURACY >> (\S+)% <<", logs[0])
+        assert m, logs[0][-1500:]
+        total = int(m.group(2))
+        # every rank trains the same number of whole bunches: at most what the smaller shard holds
+        assert 0 < total <= 2 * min(frames) and total % 64 == 0, (total, frames)
+        assert "FRAME_ACCURACY" not in logs[1]
+        models[exchange] = (tmp_path / ("out_%s_0.nnet" % exchange)).read_bytes()
+    assert models["sum"] == models["shard"]
+    assert models["sum"] != (tmp_path / "m.nnet").read_bytes()
