@@ -365,8 +365,16 @@ def test_forward_sharded_over_eight_ranks_swbd_shape_equals_single(hip, nn, tmp_
     np.testing.assert_allclose(single[utts[i][0]], O.Nnet(layers).feedforward(utts[i][1]), rtol=1e-4, atol=1e-9)
 
 
-def _run_host_ranks(tmp_path, tag, model, data, R, env_extra):
-    """R processes of tests/dp_host_rank.py on GPU 0 over one fresh exchange file -> [params of rank r]"""
+def _device_count(hip):
+    import ctypes
+    n = ctypes.c_int(0)
+    hip.call("hipK_device_count", ctypes.byref(n))
+    return n.value
+
+
+def _run_host_ranks(tmp_path, tag, model, data, R, env_extra, transport="host"):
+    """R processes of tests/dp_host_rank.py over one fresh exchange file -> [params of rank r].  transport "host": all on
+    GPU 0 with the host-staged communicator; "rccl": rank r on GPU r, RCCL."""
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     xfile = "/dev/shm/kaldi_amd_test_%d_%s" % (os.getpid(), tag)
     if os.path.exists(xfile):
@@ -374,7 +382,7 @@ def _run_host_ranks(tmp_path, tag, model, data, R, env_extra):
     env = dict(os.environ, **env_extra)
     try:
         procs = [subprocess.Popen([sys.executable, os.path.join(root, "tests", "dp_host_rank.py"), str(model), str(data), str(r),
-                                   str(R), xfile, str(tmp_path / ("%s_r%d.npz" % (tag, r)))],
+                                   str(R), ("rccl:" if transport == "rccl" else "") + xfile, str(tmp_path / ("%s_r%d.npz" % (tag, r)))],
                                   stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env) for r in range(R)]
         for p in procs:
             out, err = p.communicate(timeout=110)
@@ -385,13 +393,17 @@ def _run_host_ranks(tmp_path, tag, model, data, R, env_extra):
     return [dict(np.load(tmp_path / ("%s_r%d.npz" % (tag, r)))) for r in range(R)]
 
 
-@pytest.mark.parametrize("R", [2, 3])
-def test_real_ranks_with_their_own_rows_train_like_one_process_on_all_rows(hip, nn, tmp_path, R):
-    """R rank PROCESSES on this GPU, each with its own third / half of every bunch, joined by the host-staged
-    communicator (real reduce-scatter / all-gather / all-reduce semantics: rank-dependent shard offsets, in-place
-    buffers, pieces smaller than a layer).  After three steps with momentum, weight decay and the row-norm bound:
-    every rank holds the same bits; the sharded exchange (1 and 3 chunks) gives the bits of the summed one; and
-    the result equals one process trained on the whole bunches, and the numpy oracle, to rounding."""
+@pytest.mark.parametrize("R,transport", [(2, "host"), (3, "host"), (2, "rccl")])
+def test_real_ranks_with_their_own_rows_train_like_one_process_on_all_rows(hip, nn, tmp_path, R, transport):
+    """R rank PROCESSES, each with its own third / half of every bunch.  "host": all on this GPU, joined by the
+    host-staged communicator (real reduce-scatter / all-gather / all-reduce semantics: rank-dependent shard offsets,
+    in-place buffers, pieces smaller than a layer); "rccl": one GPU per rank over RCCL, where the box has two.
+    After three steps with momentum, weight decay and the row-norm bound: every rank holds the same bits; the
+    sharded exchange (1 and 3 chunks) equals the summed one -- bit for bit with the host transport, which adds in
+    rank order in both, to rounding with RCCL; and the result equals one process trained on the whole bunches, and
+    the numpy oracle, to rounding."""
+    if transport == "rccl" and _device_count(hip) < R:
+        pytest.skip("needs %d GPUs" % R)
     rs = np.random.RandomState(123 + R)
     dims = [40, 96, 64, 50, 33]
     data, layers = _model_bytes(rs, dims)
@@ -407,7 +419,7 @@ def test_real_ranks_with_their_own_rows_train_like_one_process_on_all_rows(hip, 
     for exchange, chunks in (("sum", "3"), ("shard", "1"), ("shard", "3")):
         tag = "%s%s" % (exchange, chunks)
         got[tag] = _run_host_ranks(tmp_path, tag, model, tmp_path / "d.npz", R,
-                                   {"KALDI_AMD_DP_EXCHANGE": exchange, "KALDI_AMD_DP_CHUNKS": chunks})
+                                   {"KALDI_AMD_DP_EXCHANGE": exchange, "KALDI_AMD_DP_CHUNKS": chunks}, transport)
         for r in range(1, R):
             for k in got[tag][0]:
                 assert np.array_equal(got[tag][0][k], got[tag][r][k]), (tag, r, k)      # replicas stay identical
@@ -416,7 +428,10 @@ def test_real_ranks_with_their_own_rows_train_like_one_process_on_all_rows(hip, 
             assert np.array_equal(l.W, got[tag][0]["W%d" % k]) and np.array_equal(l.b, got[tag][0]["b%d" % k])
     for tag in ("shard1", "shard3"):
         for k in got["sum3"][0]:
-            assert np.array_equal(got["sum3"][0][k], got[tag][0][k]), (tag, k)
+            if transport == "host":
+                assert np.array_equal(got["sum3"][0][k], got[tag][0][k]), (tag, k)
+            else:
+                np.testing.assert_allclose(got["sum3"][0][k], got[tag][0][k], rtol=1e-5, atol=1e-6)
     # one process on the whole bunches
     one = nn.Trainer(str(model))
     one.set_train_opts(*[float(v) for v in opts], True, True)
