@@ -79,6 +79,11 @@ class CuDevice {
     CU_SAFE_CALL(hipK_event_record(*ev, done));
     CU_SAFE_CALL(hipK_stream_wait_event(waiter, *ev));
   }
+  /// marks "everything queued on `done` so far" in *ev (created on first use) for a later hipK_stream_wait_event
+  void Record(khStream_t done, khEvent_t *ev) {
+    if (*ev == NULL) CU_SAFE_CALL(hipK_event_create_ordering(ev));
+    CU_SAFE_CALL(hipK_event_record(*ev, done));
+  }
   /// Blocks until everything queued on the library's streams has finished (the main stream and,
   /// where they exist, the update streams: updates put off to the next forward pass may be the last
   /// work of a training step).
@@ -104,6 +109,17 @@ class CuDevice {
   khStream_t stream_, main_stream_, side_stream_, aux_stream_, copy_stream_;
   std::map<std::string, double> profile_map_;
   KALDI_DISALLOW_COPY_AND_ASSIGN(CuDevice);
+};
+
+/// Collectives queued while one of these is alive may go out as one launch (hipK_comm_group_begin / _end); the
+/// group is closed when the scope is left, also by an exception.
+class CommGroupScope {
+ public:
+  CommGroupScope() { CU_SAFE_CALL(hipK_comm_group_begin()); }
+  ~CommGroupScope() { hipK_comm_group_end(); }
+
+ private:
+  KALDI_DISALLOW_COPY_AND_ASSIGN(CommGroupScope);
 };
 
 /// While alive, operations of the calling code are queued on `s` instead of the main stream.

@@ -25,17 +25,37 @@ namespace {
 // all-reduce), meets them again and copies the result back.  Blocking and slow by design: it exists so that the
 // multi-rank code paths -- rank-dependent shard offsets, in-place reduce-scatter and all-gather, uneven data -- run
 // with different data on every rank on a box with one GPU.
+constexpr int kHostMaxRanks = 64;
+struct HostPost {  // what a rank is about to do: compared across the ranks at the start of every collective
+  unsigned long long seq, kind, count;
+};
 struct HostCtl {
   std::atomic<unsigned> count, generation, failed;
+  HostPost post[kHostMaxRanks];
 };
 struct HostComm {
   int rank = 0, nranks = 1;
   char *base = nullptr;
   size_t map_bytes = 0, slot_bytes = 0;
+  unsigned long long seq = 0;  // collectives entered so far
+  int timeout_s = 120;
+  bool trace = false;
+  // Device copies go through this process's own pinned buffer (slot_bytes), and the CPU moves the bytes between it
+  // and the shared slots: the GPU runtime never sees the mapping the ranks share.
+  char *pinned = nullptr;
+  double t0 = 0.0;
+  double now() const {
+    timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec + 1e-9 * ts.tv_nsec - t0;
+  }
+  void say(const char *what) const {
+    if (trace) fprintf(stderr, "[host comm %9.3f ms] rank %d #%llu %s\n", 1e3 * now(), rank, seq, what);
+  }
   static constexpr size_t kCtlBytes = 4096;
   HostCtl *ctl() { return reinterpret_cast<HostCtl *>(base); }
   char *slot(int r) { return base + kCtlBytes + (size_t)r * slot_bytes; }
-  // false after two minutes without the others (a rank died): the caller reports an error instead of hanging
+  // false after timeout_s without the others (a rank died): the caller reports an error instead of hanging
   bool barrier() {
     HostCtl *c = ctl();
     if (c->failed.load()) return false;
@@ -46,9 +66,10 @@ struct HostComm {
       return true;
     }
     const time_t t0 = time(nullptr);
-    while (c->generation.load() == g) {
-      sched_yield();
-      if (c->failed.load() || time(nullptr) - t0 > 120) {
+    for (unsigned spins = 0; c->generation.load() == g; ++spins) {
+      // a short spin, then sleep: a waiting rank must not keep a core from the threads its peers' GPU runtime needs
+      if (spins < 2000) sched_yield(); else usleep(50);
+      if (c->failed.load() || time(nullptr) - t0 > timeout_s) {
         c->failed.store(1);
         return false;
       }
@@ -58,6 +79,8 @@ struct HostComm {
   void unmap() {
     if (base) munmap(base, map_bytes);
     base = nullptr;
+    if (pinned) (void)hipHostFree(pinned);
+    pinned = nullptr;
   }
 };
 
@@ -96,15 +119,47 @@ int host_fail(const char *what) {
     if (!(h)->barrier()) return host_fail("a rank did not reach the collective (timed out or failed)"); \
   } while (0)
 
+// Start of a collective: every rank posts what it is about to do, all meet, and each checks that all posted the same
+// (the n-th collective of every rank must be the same call with the same count: a mismatch is a bug in the caller
+// that a real transport would answer with a hang or with wrong sums).
+int host_begin(HostComm *h, unsigned long long kind, unsigned long long count, const char *name) {
+  HostPost &mine = h->ctl()->post[h->rank];
+  mine.seq = ++h->seq;
+  mine.kind = kind;
+  mine.count = count;
+  if (h->trace) fprintf(stderr, "[host comm %9.3f ms] rank %d #%llu %s count %llu\n", 1e3 * h->now(), h->rank, h->seq, name, count);
+  if (!h->barrier()) {
+    snprintf(kh::ctx().last_msg, sizeof(kh::ctx().last_msg),
+             "host communicator: rank %d waited %d s for the others in collective #%llu (%s, count %llu)", h->rank,
+             h->timeout_s, h->seq, name, count);
+    return KH_ERR_COMM;
+  }
+  for (int r = 0; r < h->nranks; ++r) {
+    const HostPost &o = h->ctl()->post[r];
+    if (o.seq != mine.seq || o.kind != kind || o.count != count) {
+      h->ctl()->failed.store(1);
+      snprintf(kh::ctx().last_msg, sizeof(kh::ctx().last_msg),
+               "host communicator: collective mismatch: rank %d is in #%llu (%s, count %llu), rank %d in #%llu (kind %llu, count %llu)",
+               h->rank, mine.seq, name, count, r, o.seq, o.kind, o.count);
+      return KH_ERR_COMM;
+    }
+  }
+  KH_HOST_MEET(h);  // all have compared before anyone posts its next collective
+  return KH_OK;
+}
+
 struct OpSum {
+  static constexpr int kId = 0;
   template <typename T>
   static T apply(T a, T b) { return a + b; }
 };
 struct OpMin {
+  static constexpr int kId = 1;
   template <typename T>
   static T apply(T a, T b) { return b < a ? b : a; }
 };
 struct OpMax {
+  static constexpr int kId = 2;
   template <typename T>
   static T apply(T a, T b) { return b > a ? b : a; }
 };
@@ -112,16 +167,40 @@ struct OpMax {
 // pieces[k] of n elements each, device -> this rank's slot (piece k at k * n), all behind the stream's queued work
 template <typename T>
 int host_stage_out(HostComm *h, hipStream_t st, const T *const *pieces, int npieces, size_t n) {
-  T *mine = reinterpret_cast<T *>(h->slot(h->rank));
+  T *mine = reinterpret_cast<T *>(h->pinned);
+  h->say("waits for its stream");
+  // (polling: the stream usually waits for events of the library's other streams, and the host thread queues
+  // nothing more until this collective is over)
+  for (;;) {
+    const hipError_t q = hipStreamQuery(st);
+    if (q == hipSuccess) break;
+    if (q != hipErrorNotReady) return (int)q;
+    (void)hipStreamQuery(kh::ctx().stream);
+    usleep(20);
+  }
+  h->say("copies out");
   for (int k = 0; k < npieces; ++k)
     KH_HIP(hipMemcpyAsync(mine + (size_t)k * n, pieces[k], n * sizeof(T), hipMemcpyDeviceToHost, st));
   KH_HIP(hipStreamSynchronize(st));
+  memcpy(h->slot(h->rank), h->pinned, (size_t)npieces * n * sizeof(T));
+  h->say("staged");
+  return KH_OK;
+}
+
+// n bytes of host memory (a slot, a vector) -> device, through the pinned buffer
+int host_stage_in(HostComm *h, hipStream_t st, void *dst, const void *src, size_t bytes) {
+  memcpy(h->pinned, src, bytes);
+  KH_HIP(hipMemcpyAsync(dst, h->pinned, bytes, hipMemcpyHostToDevice, st));
+  KH_HIP(hipStreamSynchronize(st));
+  h->say("copied in");
   return KH_OK;
 }
 
 // all-reduce of buf[0..count) in slot-sized chunks
 template <typename T, typename Op>
 int host_allreduce(HostComm *h, hipStream_t st, T *buf, size_t count) {
+  int rc0 = host_begin(h, 100 + sizeof(T) + 10 * Op::kId, count, "all-reduce");
+  if (rc0 != KH_OK) return rc0;
   const size_t cap = h->slot_bytes / sizeof(T);
   std::vector<T> acc;
   for (size_t off = 0; off < count; off += cap) {
@@ -136,8 +215,8 @@ int host_allreduce(HostComm *h, hipStream_t st, T *buf, size_t count) {
       for (size_t i = 0; i < n; ++i) acc[i] = Op::apply(acc[i], o[i]);
     }
     KH_HOST_MEET(h);  // every rank has read the slots before anyone refills its own
-    KH_HIP(hipMemcpyAsync(buf + off, acc.data(), n * sizeof(T), hipMemcpyHostToDevice, st));
-    KH_HIP(hipStreamSynchronize(st));
+    rc = host_stage_in(h, st, buf + off, acc.data(), n * sizeof(T));
+    if (rc != KH_OK) return rc;
   }
   return KH_OK;
 }
@@ -145,6 +224,8 @@ int host_allreduce(HostComm *h, hipStream_t st, T *buf, size_t count) {
 // in-place reduce-scatter: this rank's shard of buf becomes the rank-ordered sum of every rank's copy of that shard;
 // the other shards keep this rank's own values, as with RCCL's in-place form
 int host_reduce_scatter(HostComm *h, hipStream_t st, float *buf, size_t shard_count) {
+  int rc0 = host_begin(h, 200, shard_count, "reduce-scatter");
+  if (rc0 != KH_OK) return rc0;
   const size_t cap = h->slot_bytes / sizeof(float) / h->nranks;
   if (cap == 0) return host_fail("slot too small for a reduce-scatter over this many ranks");
   std::vector<float> acc;
@@ -162,14 +243,16 @@ int host_reduce_scatter(HostComm *h, hipStream_t st, float *buf, size_t shard_co
       for (size_t i = 0; i < n; ++i) acc[i] += o[i];
     }
     KH_HOST_MEET(h);
-    KH_HIP(hipMemcpyAsync(buf + (size_t)h->rank * shard_count + off, acc.data(), n * sizeof(float), hipMemcpyHostToDevice, st));
-    KH_HIP(hipStreamSynchronize(st));
+    rc = host_stage_in(h, st, buf + (size_t)h->rank * shard_count + off, acc.data(), n * sizeof(float));
+    if (rc != KH_OK) return rc;
   }
   return KH_OK;
 }
 
 // all-gather: rank r's `count` elements at send land at recv + r * count on every rank
 int host_allgather(HostComm *h, hipStream_t st, const float *send, float *recv, size_t count) {
+  int rc0 = host_begin(h, 300, count, "all-gather");
+  if (rc0 != KH_OK) return rc0;
   const size_t cap = h->slot_bytes / sizeof(float);
   for (size_t off = 0; off < count; off += cap) {
     const size_t n = count - off < cap ? count - off : cap;
@@ -180,9 +263,9 @@ int host_allgather(HostComm *h, hipStream_t st, const float *send, float *recv, 
     for (int r = 0; r < h->nranks; ++r) {
       float *dst = recv + (size_t)r * count + off;
       if (r == h->rank && dst == send + off) continue;
-      KH_HIP(hipMemcpyAsync(dst, h->slot(r), n * sizeof(float), hipMemcpyHostToDevice, st));
+      rc = host_stage_in(h, st, dst, h->slot(r), n * sizeof(float));
+      if (rc != KH_OK) return rc;
     }
-    KH_HIP(hipStreamSynchronize(st));
     KH_HOST_MEET(h);
   }
   return KH_OK;
@@ -223,7 +306,9 @@ KH_EXPORT int hipK_comm_init(const unsigned char id[KH_COMM_ID_BYTES], int rank,
 
 KH_EXPORT int hipK_comm_init_host(const char *path, int rank, int nranks, size_t slot_bytes) {
   KH_CHECK_INIT();
-  KH_REQUIRE(path != nullptr && nranks >= 1 && rank >= 0 && rank < nranks && slot_bytes >= 4096 && slot_bytes % 256 == 0);
+  KH_REQUIRE(path != nullptr && nranks >= 1 && nranks <= kHostMaxRanks && rank >= 0 && rank < nranks && slot_bytes >= 4096 &&
+             slot_bytes % 256 == 0);
+  static_assert(sizeof(HostCtl) <= HostComm::kCtlBytes, "control block");
   int rc = hipK_comm_destroy();
   if (rc != KH_OK) return rc;
   const int fd = open(path, O_RDWR | O_CREAT, 0600);
@@ -233,6 +318,8 @@ KH_EXPORT int hipK_comm_init_host(const char *path, int rank, int nranks, size_t
   h->nranks = nranks;
   h->slot_bytes = slot_bytes;
   h->map_bytes = HostComm::kCtlBytes + (size_t)nranks * slot_bytes;
+  if (const char *e = getenv("KALDI_HIP_COMM_TIMEOUT")) h->timeout_s = atoi(e) > 0 ? atoi(e) : h->timeout_s;
+  h->trace = getenv("KALDI_HIP_COMM_TRACE") != nullptr;
   // every rank sizes the file to the same length; bytes the file gains read as zero, which is the barrier's start state
   void *m = ftruncate(fd, (off_t)h->map_bytes) == 0 ? mmap(nullptr, h->map_bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0)
                                                     : MAP_FAILED;
@@ -242,6 +329,12 @@ KH_EXPORT int hipK_comm_init_host(const char *path, int rank, int nranks, size_t
     return host_fail("cannot size or map the exchange file");
   }
   h->base = static_cast<char *>(m);
+  h->t0 = h->now();
+  if (hipHostMalloc(reinterpret_cast<void **>(&h->pinned), slot_bytes, hipHostMallocDefault) != hipSuccess) {
+    h->unmap();
+    delete h;
+    return host_fail("cannot allocate the pinned staging buffer");
+  }
   Comm &c = comm();
   c.host = h;
   c.rank = rank;
@@ -414,8 +507,7 @@ KH_EXPORT int hipK_comm_barrier(khStream_t s) {
   if (c.host) {
     int rc = hipK_stream_synchronize(s);
     if (rc != KH_OK) return rc;
-    KH_HOST_MEET(c.host);
-    return KH_OK;
+    return host_begin(c.host, 400, 0, "barrier");
   }
   if (!c.comm) return KH_ERR_NOT_INITIALISED;
   void *ws;

@@ -85,6 +85,31 @@ static int free_workspaces() {
 
 using kh::ctx;
 
+// KALDI_HIP_SLOW_CALLS=<ms>: report (stderr) every blocking runtime call of this file that takes longer -- allocation,
+// free, synchronisation, blocking copies.  A diagnostic for stalls that are not the kernels' (a shared GPU, a
+// driver-side wait); off by default.
+namespace {
+struct SlowCall {
+  const char *what;
+  timespec t0;
+  static double limit_ms() {
+    static const double v = getenv("KALDI_HIP_SLOW_CALLS") ? atof(getenv("KALDI_HIP_SLOW_CALLS")) : 0.0;
+    return v;
+  }
+  explicit SlowCall(const char *w) : what(w) {
+    if (limit_ms() > 0.0) clock_gettime(CLOCK_MONOTONIC, &t0);
+  }
+  ~SlowCall() {
+    if (limit_ms() <= 0.0) return;
+    timespec t1;
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    const double ms = 1e3 * (t1.tv_sec - t0.tv_sec) + 1e-6 * (t1.tv_nsec - t0.tv_nsec);
+    if (ms > limit_ms()) fprintf(stderr, "[kaldi_hip] %s took %.1f ms\n", what, ms);
+  }
+};
+}  // namespace
+
+
 KH_EXPORT int hipK_device_count(int *count) {
   KH_REQUIRE(count != nullptr);
   KH_HIP(hipGetDeviceCount(count));
@@ -215,6 +240,7 @@ KH_EXPORT int hipK_stream_destroy(khStream_t stream) {
 
 KH_EXPORT int hipK_stream_synchronize(khStream_t stream) {
   KH_CHECK_INIT();
+  SlowCall sc("hipStreamSynchronize");
   KH_HIP(hipStreamSynchronize(kh::pick(stream)));
   return KH_OK;
 }
@@ -228,6 +254,7 @@ KH_EXPORT int hipK_stream_wait_event(khStream_t stream, khEvent_t ev) {
 
 KH_EXPORT int hipK_device_synchronize(void) {
   KH_CHECK_INIT();
+  SlowCall sc("hipDeviceSynchronize");
   KH_HIP(hipDeviceSynchronize());
   return KH_OK;
 }
@@ -265,6 +292,7 @@ KH_EXPORT int hipK_malloc_pitch(void **ptr, int32_t *stride_elems, int32_t rows,
   *stride_elems = (int32_t)(pitch / elem_size);
   *ptr = nullptr;
   if (rows == 0 || cols == 0) return KH_OK;
+  SlowCall sc("hipMalloc");
   KH_HIP(hipMalloc(ptr, pitch * (size_t)rows));
   return KH_OK;
 }
@@ -274,12 +302,14 @@ KH_EXPORT int hipK_malloc(void **ptr, size_t bytes) {
   KH_REQUIRE(ptr != nullptr);
   *ptr = nullptr;
   if (bytes == 0) return KH_OK;
+  SlowCall sc("hipMalloc");
   KH_HIP(hipMalloc(ptr, bytes));
   return KH_OK;
 }
 
 KH_EXPORT int hipK_free(void *ptr) {
   if (!ptr) return KH_OK;
+  SlowCall sc("hipFree");
   KH_HIP(hipFree(ptr));
   return KH_OK;
 }
@@ -289,6 +319,7 @@ KH_EXPORT int hipK_malloc_host(void **ptr, size_t bytes) {
   KH_REQUIRE(ptr != nullptr);
   *ptr = nullptr;
   if (bytes == 0) return KH_OK;
+  SlowCall sc("hipHostMalloc");
   KH_HIP(hipHostMalloc(ptr, bytes, hipHostMallocDefault));
   return KH_OK;
 }
@@ -425,6 +456,7 @@ KH_EXPORT int hipK_memcpy(khStream_t s, void *dst, const void *src, size_t bytes
   if (bytes == 0) return KH_OK;
   KH_REQUIRE(dst && src && kind >= 0 && kind <= 2);
   hipStream_t st = kh::pick(s);
+  SlowCall sc("hipK_memcpy");
   KH_HIP(hipMemcpyAsync(dst, src, bytes, to_kind(kind), st));
   if (kind != 2) KH_HIP(hipStreamSynchronize(st));
   return KH_OK;

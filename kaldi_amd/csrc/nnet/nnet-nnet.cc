@@ -248,6 +248,7 @@ void Nnet::Backpropagate(const CuMatrix<BaseFloat> &in_err, CuMatrix<BaseFloat> 
   // no back-propagation below reads what it writes.
   deferred_updates_.clear();
   deferred_layers_.clear();
+  dp_first_gather_ = NULL;
   auto update = [&](int32 i, const CuMatrix<BaseFloat> &input, const CuMatrix<BaseFloat> &err) {
     if (!overlap || !nnet_[i]->IsUpdatable()) {
       if (dp_ranks_ == 1 && group_updates_ && nnet_[i]->IsUpdatable() && nnet_[i]->GetType() == Component::kBiasedLinearity &&
@@ -290,15 +291,24 @@ void Nnet::Backpropagate(const CuMatrix<BaseFloat> &in_err, CuMatrix<BaseFloat> 
         dp_in_repack_.CopyFromMat(input);
         in_rows = dp_in_repack_.Data();
       }
-      CU_SAFE_CALL(hipF_allgather(dev.AuxStream(), in_rows, dp_in_all_[i].Data(),
-                                  static_cast<size_t>(rows) * dp_in_all_[i].Stride()));
-      CU_SAFE_CALL(hipF_allgather(dev.AuxStream(), err.Data(), dp_err_all_[i].Data(),
-                                  static_cast<size_t>(rows) * err.Stride()));
       {
-        // the updates of all layers as ONE launch on the gathered rows, behind the pass (below), where the
-        // layer's update is the single fused launch
+        CommGroupScope both;  // the two gathers of a layer go out as one launch of the collective library
+        CU_SAFE_CALL(hipF_allgather(dev.AuxStream(), in_rows, dp_in_all_[i].Data(),
+                                    static_cast<size_t>(rows) * dp_in_all_[i].Stride()));
+        CU_SAFE_CALL(hipF_allgather(dev.AuxStream(), err.Data(), dp_err_all_[i].Data(),
+                                    static_cast<size_t>(rows) * err.Stride()));
+      }
+      {
+        // the updates on the gathered rows as grouped launches behind the pass (below), where the layer's update
+        // is the single fused launch
         khAffineUpdate item;
         if (group_updates_ && bl->DescribeUpdate(dp_in_all_[i], dp_err_all_[i], &item)) {
+          // the top layer's rows arrive first: a mark behind them lets its update start while the rows of the
+          // layers below are still on the links
+          if (deferred_updates_.empty()) {
+            dev.Record(dev.AuxStream(), &grad_events_[i]);
+            dp_first_gather_ = grad_events_[i];
+          }
           deferred_updates_.push_back(item);
           deferred_layers_.push_back(i);
           aux_used = true;
@@ -463,10 +473,23 @@ void Nnet::Backpropagate(const CuMatrix<BaseFloat> &in_err, CuMatrix<BaseFloat> 
   }
   for (size_t k = 0; k < pending.size(); ++k) update(pending[k].i, *pending[k].input, *pending[k].err);
   if (!deferred_updates_.empty()) {
-    // (data-parallel gather exchange: the rows of every rank have to be in first)
-    if (dp_ranks_ > 1) dev.Order(dev.AuxStream(), dev.MainStream(), &aux_join_event_);
     CuProfileScope p("BiasedLinearity::Update");
-    CU_SAFE_CALL(hipF_affine_update_group(dev.Stream(), static_cast<int32>(deferred_updates_.size()), &deferred_updates_[0]));
+    size_t first = 0;
+    if (dp_ranks_ > 1) {
+      // Data-parallel gather exchange: the rows of every rank have to be in first.  Where the top layer is a large
+      // part of the work (the output layer of an acoustic model), its update is a launch of its own that only
+      // waits for its own rows -- gathered first -- and runs beside the gathers of the layers below.
+      double all = 0.0;
+      for (size_t k = 0; k < deferred_updates_.size(); ++k) all += static_cast<double>(deferred_updates_[k].O) * deferred_updates_[k].I;
+      const double top = static_cast<double>(deferred_updates_[0].O) * deferred_updates_[0].I;
+      if (deferred_updates_.size() > 1 && dp_first_gather_ != NULL && top >= 0.25 * all) {
+        CU_SAFE_CALL(hipK_stream_wait_event(dev.MainStream(), dp_first_gather_));
+        CU_SAFE_CALL(hipF_affine_update_group(dev.Stream(), 1, &deferred_updates_[0]));
+        first = 1;
+      }
+      dev.Order(dev.AuxStream(), dev.MainStream(), &aux_join_event_);
+    }
+    CU_SAFE_CALL(hipF_affine_update_group(dev.Stream(), static_cast<int32>(deferred_updates_.size() - first), &deferred_updates_[first]));
     for (size_t k = 0; k < deferred_layers_.size(); ++k)
       static_cast<BiasedLinearity *>(nnet_[deferred_layers_[k]])->AfterGroupedUpdate();
   }
@@ -751,8 +774,12 @@ void Nnet::SetDataParallel(int32 nranks) {
   //          n x 256 rows (n times the update FLOPs, no gradient buffers, replicas identical by construction).
   //  sum:    all-reduce of each layer's gradient, the whole step on every rank (also what a network takes that
   //          cannot use the arenas: an L1 penalty, an updatable component of another kind).
-  dp_gather_ = false;
-  dp_shard_ = nranks >= 2;
+  // Default by the number of ranks, from the bytes a link carries per step (xGMI is point to point: n ranks of one
+  // node have one link per pair).  Switchboard net, 256-frame bunch: gather sends 40 MB to every peer whatever n is;
+  // shard and sum move 2/n x 185 MB over every link -- 185 MB for 2 ranks, 92 for 4, 46 for 8.  Gather pays with n
+  // times the update FLOPs (a third of the step each), so it wins while the links are the bound: 2 to 4 ranks.
+  dp_gather_ = nranks >= 2 && nranks <= 4;
+  dp_shard_ = nranks > 4;
   if (const char *e = getenv("KALDI_AMD_DP_EXCHANGE")) {
     dp_gather_ = nranks >= 2 && std::string(e) == "gather";
     dp_shard_ = nranks >= 2 && std::string(e) == "shard";

@@ -137,6 +137,7 @@ class Nnet {
   std::vector<BaseFloat *> dp_layer_grad_;  // data-parallel: one gradient buffer per layer
   std::vector<size_t> dp_layer_grad_size_;
   khEvent_t join_event_, aux_join_event_;
+  khEvent_t dp_first_gather_ = NULL;  // gather exchange: behind the gathers of the top layer's rows (owned by grad_events_)
   // sharded exchange: the parameter arenas (weights, gradients, momentum state: one layout) and their chunks
   std::vector<DpChunk> dp_chunks_;
   std::vector<int32> dp_chunk_of_layer_;
