@@ -508,6 +508,9 @@ def main():
                        "global_bunch": BUNCH * world if kind != "forward" else None,
                        "frames_per_step": round(done / args.steps, 1),
                        "parallelism": ("single" if world == 1 else "dp%d" % world if kind == "train" else "replicas%d" % world),
+                       # (Nnet::SetDataParallel's rule: rows gathered for 2-4 ranks, sharded gradient sums above)
+                       "exchange": (None if world == 1 or kind != "train" else
+                                    os.environ.get("KALDI_AMD_DP_EXCHANGE") or ("gather" if world <= 4 else "shard")),
                        "flops_per_frame": fpf,
                        "pct_fp32_mfma_peak_end_to_end": round(100.0 * value * fpf / world / (F32_MFMA_PEAK_TFLOPS * 1e12), 2)},
             # frac = algorithmic FLOPs of the GEMM launches / summed launch durations / peak: what the per-kernel
