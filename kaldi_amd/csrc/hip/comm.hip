@@ -169,15 +169,7 @@ template <typename T>
 int host_stage_out(HostComm *h, hipStream_t st, const T *const *pieces, int npieces, size_t n) {
   T *mine = reinterpret_cast<T *>(h->pinned);
   h->say("waits for its stream");
-  // (polling: the stream usually waits for events of the library's other streams, and the host thread queues
-  // nothing more until this collective is over)
-  for (;;) {
-    const hipError_t q = hipStreamQuery(st);
-    if (q == hipSuccess) break;
-    if (q != hipErrorNotReady) return (int)q;
-    (void)hipStreamQuery(kh::ctx().stream);
-    usleep(20);
-  }
+  KH_HIP(hipStreamSynchronize(st));
   h->say("copies out");
   for (int k = 0; k < npieces; ++k)
     KH_HIP(hipMemcpyAsync(mine + (size_t)k * n, pieces[k], n * sizeof(T), hipMemcpyDeviceToHost, st));
