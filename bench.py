@@ -343,11 +343,11 @@ class Workload:
 
 
 def measure(W, h, nn, fence, steps, warmup, setup_steps=40, sync=None):
-    """set-up steps, a pass with every GEMM launch bracketed by HIP events (the roofline), warm-up, `steps` timed steps.
+    """set-up steps, a pass with every GEMM launch timed by HIP events bound to it (the roofline), warm-up, `steps` timed steps.
     -> dict of raw figures (this rank's)."""
-    # Roofline of the dominant kernel, measured first: the same steps with every GEMM launch bracketed by HIP
-    # events on the stream it is queued on (a pass of its own: the event markers must not sit inside the timed
-    # region).  This pass also takes the GPU out of its idle clock state: from idle the shader clock needs
+    # Roofline of the dominant kernel, measured first: the same steps with a start and a stop event bound to every
+    # GEMM launch on the stream it is queued on (the kernel's own begin and end stamps; a pass of its own: a timed
+    # dispatch costs the host and the queue a little, which must not sit inside the timed region).  This pass also takes the GPU out of its idle clock state: from idle the shader clock needs
     # ~13-20 ms of load to climb from 2.14 to 2.40 GHz (tools/clock_ramp.hip), which is most of a 20-step run.
     roof_steps = max(30, min(steps, 50))
     for i in range(setup_steps):
@@ -532,7 +532,7 @@ def main():
                                          "achieved": round(v[2] / v[1] * 1e3 if v[1] else 0.0, 2),
                                          "frac": round(v[2] / v[1] * 1e3 / F32_MFMA_PEAK_TFLOPS if v[1] else 0.0, 4)}
                                         for k, v in sorted(classes.items())]},
-            "order": "40 set-up steps (first touch; the clock climbs out of its idle state), %d steps with GEMM launches bracketed by events (roofline), %d warm-up steps, %d timed steps" % (roof_steps, args.warmup, args.steps),
+            "order": "40 set-up steps (first touch; the clock climbs out of its idle state), %d steps with HIP events bound to every GEMM launch (roofline), %d warm-up steps, %d timed steps" % (roof_steps, args.warmup, args.steps),
             "check": check,
         }
         if replicas is not None:

@@ -240,7 +240,8 @@ int hipF_gemm(khStream_t s, int transA, int transB, int32_t M, int32_t N, int32_
               const float *A, int32_t lda, const float *B, int32_t ldb, float beta, float *C, int32_t ldc);
 
 /* Measurement aid: with timing enabled every GEMM main-kernel launch (hipF_gemm and the fused
- * affine / rbm entry points) is bracketed by two HIP events on its stream.  hipK_gemm_timing_read
+ * affine / rbm entry points) carries two HIP events BOUND to the dispatch (they read the kernel's own begin
+ * and end stamps, as a kernel trace does, and put no packet of their own into the stream).  hipK_gemm_timing_read
  * blocks until they have completed, returns the summed kernel time, the time during which at
  * least one of them was running (launches queued on two streams overlap, so this is less than the
  * sum), the number of launches and their algorithmic FLOPs (2*M*N*K each), and clears the record.

@@ -170,22 +170,29 @@ hipEvent_t timing_event() {
   }
   return e;
 }
+// The pair of events a timed launch carries (see KHG_LAUNCH in gemm_kernel.h): set for the one kernel launch inside a
+// TimedLaunch scope, null otherwise.
+}  // namespace
+namespace khg {
+hipEvent_t g_bind_start = nullptr, g_bind_stop = nullptr;
+}
+namespace {
 struct TimedLaunch {
   hipEvent_t e0 = nullptr, e1 = nullptr;
-  hipStream_t st;
   double fl_;
-  TimedLaunch(hipStream_t s, double fl) : st(s), fl_(fl) {
+  TimedLaunch(hipStream_t, double fl) : fl_(fl) {
     if (!timing().enabled) return;
     e0 = timing_event();
     e1 = timing_event();
     if (e0 && e1) {
-      (void)hipEventRecord(e0, st);
+      khg::g_bind_start = e0;
+      khg::g_bind_stop = e1;
       timing().flops += fl;
     }
   }
   ~TimedLaunch() {
+    khg::g_bind_start = khg::g_bind_stop = nullptr;
     if (e0 && e1) {
-      (void)hipEventRecord(e1, st);
       timing().spans.push_back(std::make_pair(e0, e1));
       timing().span_flops.push_back(fl_);
     }
@@ -583,9 +590,9 @@ KH_EXPORT int hipK_gemm_timing_read(double *total_ms, double *busy_ms, long long
     KH_HIP(hipEventSynchronize(t.spans[i].second));
     float one = 0.f, off = 0.f;
     KH_HIP(hipEventElapsedTime(&one, t.spans[i].first, t.spans[i].second));
-    if (i > 0) {
-      KH_HIP(hipEventSynchronize(t.spans[i].first));
-      KH_HIP(hipEventElapsedTime(&off, t.spans[0].first, t.spans[i].first));
+    if (i > 0) {  // (begin of launch i = its end, measured from the first launch's begin, less its length)
+      KH_HIP(hipEventElapsedTime(&off, t.spans[0].first, t.spans[i].second));
+      off -= one;
     }
     ms += one;
     iv.push_back(std::make_pair((double)off, (double)off + one));
@@ -625,7 +632,10 @@ KH_EXPORT int hipK_gemm_timing_spans(double *start_ms, double *dur_ms, double *g
     KH_HIP(hipEventSynchronize(t.spans[i].second));
     float one = 0.f, off = 0.f;
     KH_HIP(hipEventElapsedTime(&one, t.spans[i].first, t.spans[i].second));
-    if (i > 0) KH_HIP(hipEventElapsedTime(&off, t.spans[0].first, t.spans[i].first));
+    if (i > 0) {
+      KH_HIP(hipEventElapsedTime(&off, t.spans[0].first, t.spans[i].second));
+      off -= one;
+    }
     start_ms[i] = off;
     dur_ms[i] = one;
     if (gflop) gflop[i] = i < (int)t.span_flops.size() ? t.span_flops[i] * 1e-9 : 0.0;

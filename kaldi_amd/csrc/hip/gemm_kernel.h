@@ -121,6 +121,17 @@ template <int EPI>
 void launch_reduce(hipStream_t st, const GemmParams &p, const float *slabs, int ld_slab);
 
 #ifdef KHG_DEFINE_KERNELS
+// Launches of the product kernels.  While a launch is being timed (hipK_gemm_timing), a start and a stop event are
+// BOUND to the dispatch (hipExtLaunchKernelGGL): they read the kernel's own begin and end stamps -- what a kernel trace
+// reports -- and put no packet of their own into the stream's queue.
+extern hipEvent_t g_bind_start, g_bind_stop;
+#define KHG_LAUNCH(kern, grid, block, lds, st, ...)                                                                 \
+  do {                                                                                                              \
+    if (khg::g_bind_stop != nullptr)                                                                                \
+      hipExtLaunchKernelGGL(kern, grid, block, lds, st, khg::g_bind_start, khg::g_bind_stop, 0, __VA_ARGS__);       \
+    else                                                                                                            \
+      hipLaunchKernelGGL(kern, grid, block, lds, st, __VA_ARGS__);                                                  \
+  } while (0)
 #include <hip/hip_ext.h>
 
 #ifdef KH_GEMM_STAMPS
@@ -1341,8 +1352,8 @@ __global__ __launch_bounds__(BIG ? 512 : 256) __attribute__((amdgpu_waves_per_eu
 }
 
 void launch_update_group(hipStream_t st, const GemmGroup &g, bool big) {
-  if (big) hipLaunchKernelGGL(gemm_update_group_kernel<true>, dim3(g.first[g.n]), dim3(512), 0, st, g);
-  else hipLaunchKernelGGL(gemm_update_group_kernel<false>, dim3(g.first[g.n]), dim3(256), 0, st, g);
+  if (big) KHG_LAUNCH(gemm_update_group_kernel<true>, dim3(g.first[g.n]), dim3(512), 0, st, g);
+  else KHG_LAUNCH(gemm_update_group_kernel<false>, dim3(g.first[g.n]), dim3(256), 0, st, g);
 }
 #endif  // KHG_DEFINE_UPDATE_GROUP
 
@@ -1391,8 +1402,8 @@ __global__ __launch_bounds__(256) void gemm_chain_kernel(GemmChain g) {
 
 void launch_forward_chain(hipStream_t st, const GemmChain &g, int cfg) {
   const int nblk = g.p[0].tiles_m * g.p[0].tiles_n;
-  if (cfg == 4) hipLaunchKernelGGL((gemm_chain_kernel<32, 64, 2>), dim3(nblk), dim3(256), 0, st, g);
-  else hipLaunchKernelGGL((gemm_chain_kernel<32, 32, 4>), dim3(nblk), dim3(256), 0, st, g);
+  if (cfg == 4) KHG_LAUNCH((gemm_chain_kernel<32, 64, 2>), dim3(nblk), dim3(256), 0, st, g);
+  else KHG_LAUNCH((gemm_chain_kernel<32, 32, 4>), dim3(nblk), dim3(256), 0, st, g);
 }
 #endif  // KHG_DEFINE_CHAIN
 
@@ -1419,8 +1430,10 @@ void launch_grad_group(hipStream_t st, const GemmGroup &g, bool big, hipEvent_t 
   // An event recorded behind the launch is a packet of its own in the stream's queue, and the launch after it waits
   // ~6 us for it (kernel trace of the data-parallel step); bound to the launch itself (hipExtLaunchKernelGGL's stop
   // event) the event is the kernel's own completion signal and the queue holds nothing extra.
-  if (big) hipExtLaunchKernelGGL(gemm_grad_group_kernel<true>, dim3(g.first[g.n]), dim3(512), 0, st, nullptr, done, 0, g);
-  else hipExtLaunchKernelGGL(gemm_grad_group_kernel<false>, dim3(g.first[g.n]), dim3(256), 0, st, nullptr, done, 0, g);
+  // (a launch that is being timed carries the timing's pair instead; its caller then marks `done` on its own)
+  hipEvent_t start = done ? nullptr : g_bind_start, stop = done ? done : g_bind_stop;
+  if (big) hipExtLaunchKernelGGL(gemm_grad_group_kernel<true>, dim3(g.first[g.n]), dim3(512), 0, st, start, stop, 0, g);
+  else hipExtLaunchKernelGGL(gemm_grad_group_kernel<false>, dim3(g.first[g.n]), dim3(256), 0, st, start, stop, 0, g);
 }
 #endif  // KHG_DEFINE_GRAD_GROUP
 
@@ -1457,14 +1470,14 @@ void launch_cfg(hipStream_t st, const GemmParams &p, bool vec) {
   // Switchboard-sized nets)
   if constexpr ((EPI == EPI_BIAS_ACT || EPI == EPI_DSIG || EPI == EPI_BIAS_SAMPLE) && WK > 1 && KH_SCHED >= 2) {
     if (vec && p.splitk == 1 && p.a_bytes > 0 && p.K % (kBK * WK) != 0 && (((AK || BK_) ? (p.K & 3) : 0) == 0)) {
-      hipLaunchKernelGGL((gemm_kernel<BM, BN, kBK, WK, AK, BK_, EPI, true, true>), dim3(nblk), dim3(256), p.dyn_lds, st, p);
+      KHG_LAUNCH((gemm_kernel<BM, BN, kBK, WK, AK, BK_, EPI, true, true>), dim3(nblk), dim3(256), p.dyn_lds, st, p);
       return;
     }
   }
   if (vec)
-    hipLaunchKernelGGL((gemm_kernel<BM, BN, kBK, WK, AK, BK_, EPI, true>), dim3(nblk), dim3(256), p.dyn_lds, st, p);
+    KHG_LAUNCH((gemm_kernel<BM, BN, kBK, WK, AK, BK_, EPI, true>), dim3(nblk), dim3(256), p.dyn_lds, st, p);
   else
-    hipLaunchKernelGGL((gemm_kernel<BM, BN, kBK, WK, AK, BK_, EPI, false>), dim3(nblk), dim3(256), p.dyn_lds, st, p);
+    KHG_LAUNCH((gemm_kernel<BM, BN, kBK, WK, AK, BK_, EPI, false>), dim3(nblk), dim3(256), p.dyn_lds, st, p);
 }
 
 template <bool AK, bool BK_, int EPI>

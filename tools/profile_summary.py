@@ -26,7 +26,7 @@ f = one("/kt/**/*kernel_stats.csv")
 if f:
     rows = list(csv.DictReader(open(f)))
     tot = sum(float(r["TotalDurationNs"]) for r in rows)
-    lines += ["### kernel trace (`rocprofv3 --kernel-trace --stats`, durations include the dispatch gap before the kernel)", "",
+    lines += ["### kernel trace (`rocprofv3 --kernel-trace --stats`, begin-to-end stamps of every launch of the process, set-up and timed-dispatch passes included)", "",
               "| kernel | calls | total ms | avg us | min us | max us | % |", "|---|---:|---:|---:|---:|---:|---:|"]
     for r in rows:
         lines.append("| `%s` | %s | %.3f | %.2f | %.2f | %.2f | %.1f |" % (
