@@ -114,6 +114,66 @@ __global__ __launch_bounds__(256) void ew_kernel(EwArgs A, MatrixDim d) {
   }
 }
 
+// 16-byte accesses of data that is touched once (-DKH_EW_NT=0: plain accesses, for A/B builds)
+typedef float ew_f4 __attribute__((ext_vector_type(4)));
+#ifndef KH_EW_NT
+#define KH_EW_NT 1
+#endif
+__device__ __forceinline__ float4 ld_stream(const float *p) {
+#if KH_EW_NT
+  const ew_f4 v = __builtin_nontemporal_load(reinterpret_cast<const ew_f4 *>(p));
+  return make_float4(v.x, v.y, v.z, v.w);
+#else
+  return *reinterpret_cast<const float4 *>(p);
+#endif
+}
+__device__ __forceinline__ void st_stream(float *p, float4 o) {
+#if KH_EW_NT
+  ew_f4 v = {o.x, o.y, o.z, o.w};
+  __builtin_nontemporal_store(v, reinterpret_cast<ew_f4 *>(p));
+#else
+  *reinterpret_cast<float4 *>(p) = o;
+#endif
+}
+
+// Large matrices: the 16-byte elements of all rows are dealt out to the threads as one flat sequence (no idle lanes
+// whatever the row length -- 1320 columns fill 330 of a row's 512 lane slots in the kernel above), and a thread has
+// UNROLL elements' loads in flight before it computes and stores.
+template <class Op, int UNROLL>
+__global__ __launch_bounds__(256) void ew_flat_kernel(EwArgs A, MatrixDim d, unsigned c4_per_row, unsigned total4) {
+  const unsigned nthreads = gridDim.x * 256;
+  unsigned e = blockIdx.x * 256 + threadIdx.x;
+  for (; e < total4; e += nthreads * UNROLL) {
+    float4 m[UNROLL], a[UNROLL], b[UNROLL], cv[UNROLL];
+    float rv[UNROLL];
+    size_t idx[UNROLL];
+    bool on[UNROLL];
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      const unsigned eu = e + u * nthreads;
+      on[u] = eu < total4;
+      const unsigned r = on[u] ? eu / c4_per_row : 0, c = on[u] ? (eu - r * c4_per_row) * 4 : 0;
+      idx[u] = (size_t)r * d.stride + c;
+      if (Op::kReadDst) m[u] = *reinterpret_cast<const float4 *>(A.dst + idx[u]);
+      if (Op::kUseA) a[u] = ld_stream(A.a + idx[u]);
+      if (Op::kUseB) b[u] = ld_stream(A.b + idx[u]);
+      if (Op::kColV) cv[u] = *reinterpret_cast<const float4 *>(A.colv + c);
+      rv[u] = Op::kRowV ? A.rowv[r] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      if (!on[u]) continue;
+      float4 o;
+      o.x = Op::apply(Op::kReadDst ? m[u].x : 0.f, Op::kUseA ? a[u].x : 0.f, Op::kUseB ? b[u].x : 0.f, Op::kColV ? cv[u].x : 0.f, rv[u], A.p0, A.p1);
+      o.y = Op::apply(Op::kReadDst ? m[u].y : 0.f, Op::kUseA ? a[u].y : 0.f, Op::kUseB ? b[u].y : 0.f, Op::kColV ? cv[u].y : 0.f, rv[u], A.p0, A.p1);
+      o.z = Op::apply(Op::kReadDst ? m[u].z : 0.f, Op::kUseA ? a[u].z : 0.f, Op::kUseB ? b[u].z : 0.f, Op::kColV ? cv[u].z : 0.f, rv[u], A.p0, A.p1);
+      o.w = Op::apply(Op::kReadDst ? m[u].w : 0.f, Op::kUseA ? a[u].w : 0.f, Op::kUseB ? b[u].w : 0.f, Op::kColV ? cv[u].w : 0.f, rv[u], A.p0, A.p1);
+      if (Op::kReadDst) *reinterpret_cast<float4 *>(A.dst + idx[u]) = o;
+      else st_stream(A.dst + idx[u], o);
+    }
+  }
+}
+
 template <class Op>
 int launch_ew(khStream_t s, EwArgs A, MatrixDim d) {
   KH_CHECK_INIT();
@@ -128,6 +188,15 @@ int launch_ew(khStream_t s, EwArgs A, MatrixDim d) {
                    (!Op::kUseA || kh::aligned16(A.a)) && (!Op::kUseB || kh::aligned16(A.b)) &&
                    (!Op::kColV || kh::aligned16(A.colv));
   hipStream_t st = kh::pick(s);
+  const unsigned long long total4 = (unsigned long long)d.rows * (d.cols / 4);
+  if (vec && total4 >= (1ull << 20) && total4 < (1ull << 31)) {
+    constexpr int kUnroll = 4;
+    static const int flat_blocks = getenv("KALDI_HIP_EW_BLOCKS") ? atoi(getenv("KALDI_HIP_EW_BLOCKS")) : 65536;
+    unsigned blocks = (unsigned)((total4 + 256 * kUnroll - 1) / (256 * kUnroll));
+    if (blocks > (unsigned)flat_blocks) blocks = flat_blocks;
+    hipLaunchKernelGGL((ew_flat_kernel<Op, kUnroll>), dim3(blocks), dim3(256), 0, st, A, d, (unsigned)(d.cols / 4), (unsigned)total4);
+    return kh::launch_status();
+  }
   const int per = vec ? 4 : 1;
   const int gx = (d.cols + 256 * per - 1) / (256 * per);
   // enough row-blocks to give every CU several waves, never more rows than exist

@@ -23,6 +23,35 @@ __global__ __launch_bounds__(256) void randomize_kernel(float *y, const float *x
   }
 }
 
+// The same for a whole cache of frames: the 16-byte elements of all rows are dealt out to the threads as one flat
+// sequence (a 1320-column row fills 330 of the 512 lane slots the per-row kernel gives it), four per thread with their
+// loads in flight together, through accesses that do not keep the lines in the caches.
+typedef float gather_f4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void randomize_flat_kernel(float *y, const float *x, const int32_t *copy_from,
+                                                             MatrixDim d_out, MatrixDim d_in, unsigned c4_per_row,
+                                                             unsigned total4) {
+  constexpr int U = 4;
+  const unsigned nthreads = gridDim.x * 256;
+  for (unsigned e = blockIdx.x * 256 + threadIdx.x; e < total4; e += nthreads * U) {
+    gather_f4 v[U];
+    size_t dst[U];
+    bool on[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const unsigned eu = e + u * nthreads;
+      on[u] = eu < total4;
+      const unsigned r = on[u] ? eu / c4_per_row : 0, c = on[u] ? (eu - r * c4_per_row) * 4 : 0;
+      const int src = copy_from[r];
+      on[u] = on[u] && src >= 0 && src < d_in.rows;  // never read outside x
+      dst[u] = (size_t)r * d_out.stride + c;
+      if (on[u]) v[u] = __builtin_nontemporal_load(reinterpret_cast<const gather_f4 *>(x + (size_t)src * d_in.stride + c));
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (on[u]) __builtin_nontemporal_store(v[u], reinterpret_cast<gather_f4 *>(y + dst[u]));
+  }
+}
+
 // y[r, k*D + c] = x[clamp(r + off[k]), c]
 __global__ __launch_bounds__(256) void expand_kernel(float *y, const float *x, const int32_t *off, MatrixDim d_out,
                                                      MatrixDim d_in) {
@@ -67,6 +96,14 @@ KH_EXPORT int hipF_randomize(khStream_t s, float *y, const float *x, const int32
   KH_REQUIRE(y && x && copy_from);
   const bool vec = d_out.cols % 4 == 0 && d_out.stride % 4 == 0 && d_in.stride % 4 == 0 && kh::aligned16(y) &&
                    kh::aligned16(x);
+  const unsigned long long total4 = (unsigned long long)d_out.rows * (d_out.cols / 4);
+  if (vec && total4 >= (1ull << 20) && total4 < (1ull << 31)) {
+    unsigned blocks = (unsigned)((total4 + 1023) / 1024);
+    if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(randomize_flat_kernel, dim3(blocks), dim3(256), 0, kh::pick(s), y, x, copy_from, d_out, d_in,
+                       (unsigned)(d_out.cols / 4), (unsigned)total4);
+    return kh::launch_status();
+  }
   const int grid = d_out.rows < 16384 ? d_out.rows : 16384;
   if (vec)
     hipLaunchKernelGGL((randomize_kernel<4>), dim3(grid), dim3(256), 0, kh::pick(s), y, x, copy_from, d_out, d_in);

@@ -314,6 +314,43 @@ def test_gathers(hip):
     assert (got[:, good] == feats[:, cidx[good]]).all() and np.isposinf(got[:, 7]).all()
 
 
+def test_cache_sized_streaming_kernels(hip):
+    """The flat forms that element-wise passes and the frame shuffle take from 2^20 16-byte elements up (a whole
+    frame cache): the shuffle bit for bit, the element-wise results against numpy,
+    a row count that does not fill the last thread's four elements, an index outside the source (row left alone)."""
+    h = hip
+    rs = np.random.RandomState(23)
+    R, C = 3301, 1320                                   # 3301 * 330 = 1,089,330 elements of 16 bytes
+    src = rnd((R, C), 24)
+    idx = rs.permutation(R).astype(np.int32)
+    idx[5] = R + 3                                      # outside x: row 5 of the output keeps its contents
+    d, di = dev(h, src), dev(h, idx, False)
+    out = dev(h, np.full((R, C), 7.0, f32))
+    h.call("hipF_randomize", None, out.ptr, d.ptr, di.ptr, out.dim, d.dim)
+    got = out.numpy()
+    ok = np.arange(R) != 5
+    assert (got[ok] == src[idx[ok]]).all() and (got[5] == 7.0).all()
+    # element-wise: y = a*x + b*y, y = x*(1-x)*e, column-vector and row-vector operands
+    x, y = rnd((R, C), 25), rnd((R, C), 26)
+    dx, dy = dev(h, x), dev(h, y)
+    h.call("hipF_add_mat", None, f32(-0.25), dx.ptr, f32(0.5), dy.ptr, dx.dim)
+    close(dy.numpy(), f32(-0.25) * x + f32(0.5) * y)
+    e, yy = rnd((R, C), 27), np.random.RandomState(28).random_sample((R, C)).astype(f32)
+    de, dyy, dd = dev(h, e), dev(h, yy), dev(h, np.zeros((R, C), f32))
+    h.call("hipF_diff_sigmoid", None, dd.ptr, de.ptr, dyy.ptr, de.dim)
+    close(dd.numpy(), yy * (f32(1.0) - yy) * e)
+    col, row = rnd((C,), 29), rnd((R,), 30)
+    dm = dev(h, x)
+    h.call("hipF_add_vec_to_rows", None, f32(2.0), dev(h, col, False).ptr, f32(1.0), dm.ptr, dm.dim)
+    close(dm.numpy(), f32(2.0) * col[None, :] + x)
+    dm = dev(h, x)
+    h.call("hipF_add_vec_to_cols", None, f32(2.0), dev(h, row, False).ptr, f32(1.0), dm.ptr, dm.dim)
+    close(dm.numpy(), f32(2.0) * row[:, None] + x)
+    ds = dev(h, np.zeros((R, C), f32))
+    h.call("hipF_sigmoid", None, ds.ptr, dx.ptr, dx.dim)
+    close(ds.numpy(), O.sigmoid(x))
+
+
 def test_hybrid_taus_bit_exact_vs_oracle_parity_unpinned(hip):
     """HybridTaus streams against the oracle's restatement of cu-randkernels.cu:44-94, bit for bit.  Parity unpinned:
     the reference holds no vector for its generator and its kernels need nvcc, so nothing it produced can be compared."""

@@ -39,9 +39,9 @@ def cases(R, C):
     e = R * C
     return keep, [
         # name, kernel, algorithmic bytes (reads + writes of the matrices), call
-        ("sigmoid", "ew_kernel", 8 * e, lambda: h.call("hipF_sigmoid", None, y.ptr, x.ptr, x.dim)),
-        ("diff_sigmoid", "ew_kernel", 12 * e, lambda: h.call("hipF_diff_sigmoid", None, y.ptr, x.ptr, z.ptr, x.dim)),
-        ("add_mat (SGD step W -= lr*corr)", "ew_kernel", 12 * e, lambda: h.call("hipF_add_mat", None, f32(-0.008), x.ptr, f32(1.0), y.ptr, x.dim)),
+        ("sigmoid", "ew_", 8 * e, lambda: h.call("hipF_sigmoid", None, y.ptr, x.ptr, x.dim)),
+        ("diff_sigmoid", "ew_", 12 * e, lambda: h.call("hipF_diff_sigmoid", None, y.ptr, x.ptr, z.ptr, x.dim)),
+        ("add_mat (SGD step W -= lr*corr)", "ew_", 12 * e, lambda: h.call("hipF_add_mat", None, f32(-0.008), x.ptr, f32(1.0), y.ptr, x.dim)),
         ("softmax", "softmax", 8 * e, lambda: h.call("hipF_softmax", None, y.ptr, x.ptr, x.dim)),
         ("xent_eval (argmax + diff + loss)", "xent_rows", 8 * e, lambda: h.call("hipF_xent_eval", None, z.ptr, tgt.ptr, y.ptr, lp.ptr, ids.ptr, cnt.ptr, loss.ptr, z.dim)),
         ("find_row_max_id", "find_row_max_id", 4 * e, lambda: h.call("hipF_find_row_max_id", None, x.ptr, None, ids.ptr, x.dim)),
