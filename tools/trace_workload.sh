@@ -1,5 +1,5 @@
 #!/bin/bash
-# kernel trace + per-kernel stats of one bench workload.  usage: tools/r3_trace_wl.sh <workload>
+# kernel trace + per-kernel stats of one bench workload.  usage: tools/trace_workload.sh <workload>
 set -e
 ROOT=$(pwd); wl=$1
 out=$ROOT/gpurun_out/trace_$wl
