@@ -513,6 +513,14 @@ def main():
                        "frames_per_step": round(done / args.steps, 1),
                        "parallelism": ("single" if world == 1 else "dp%d" % world if kind == "train" else "replicas%d" % world),
                        # (Nnet::SetDataParallel's rule: rows gathered for 2-4 ranks, sharded gradient sums above)
+                       # one-GPU rehearsal of the data-parallel step: what the stand-in communicator did
+                       "rehearsal": ({"stand_in_ranks": int(os.environ["KALDI_BENCH_LOOPBACK_DP"]),
+                                      "exchange": os.environ.get("KALDI_AMD_DP_EXCHANGE") or
+                                      ("gather" if int(os.environ["KALDI_BENCH_LOOPBACK_DP"]) <= 4 else "shard"),
+                                      "stand_in": ("one rank's device work (timing only: the other shards are never stepped)"
+                                                   if os.environ.get("KALDI_BENCH_LOOPBACK_ONE_RANK") else
+                                                   "every rank's sums and steps on this GPU (the whole job's arithmetic)")}
+                                     if world == 1 and kind == "train" and os.environ.get("KALDI_BENCH_LOOPBACK_DP") else None),
                        "exchange": (None if world == 1 or kind != "train" else
                                     os.environ.get("KALDI_AMD_DP_EXCHANGE") or ("gather" if world <= 4 else "shard")),
                        "flops_per_frame": fpf,
