@@ -35,6 +35,8 @@ class Cache {
   bool Full() { return state_ == FULL; }
   bool Empty() { return state_ == EMPTY || filling_pos_ < bunchsize_; }
   bool Randomized() { return randomized_; }
+  /// rows are waiting to be shuffled / handed out (what Randomize() requires)
+  bool HoldsRows() { return state_ == FULL || state_ == FILLING; }
   /// whole bunches GetBunch can still hand out before Empty()
   int32 NumBunches() {
     if (Empty()) return 0;

@@ -153,8 +153,9 @@ int main(int argc, char *argv[]) {
         if (dist.num_ranks == 1) throw;
         fill_error = e.what();
       }
-      // (a rank whose shard has run dry holds nothing to shuffle: it takes part in the collectives with 0 bunches)
-      if (!crossvalidate && randomize && fill_error.empty() && cache.NumBunches() > 0) cache.Randomize();
+      // (Like the reference, also a last cache that holds less than one bunch is shuffled -- its line says [RND] --
+      // but a rank whose shard has run dry holds nothing to shuffle: it takes part in the collectives with 0 bunches.)
+      if (!crossvalidate && randomize && fill_error.empty() && cache.HoldsRows()) cache.Randomize();
       std::cerr << "Cache #" << ++num_cache << " " << (cache.Randomized() ? "[RND]" : "[NO-RND]")
                 << " segments: " << num_done << " frames: " << tot_t << "\n";
 

@@ -387,6 +387,23 @@ def test_train_tool_matches_reference(hip, nn, tmp_path, name, opts):
                 np.testing.assert_allclose(a.b, b.b, rtol=5e-5, atol=5e-6)
 
 
+def test_train_tool_shuffles_a_last_cache_shorter_than_a_bunch(hip, nn, tmp_path):
+    """A table that ends with fewer frames than one bunch: the reference shuffles whatever the cache holds before it
+    looks for bunches (nnetbin/nnet-train-xent-hardlab-frmshuff.cc:157-165), so its line says [RND] although no frame
+    is trained -- found by running the tools beside the reference's on random tables (tools/diff_fuzz.py)."""
+    rs = np.random.RandomState(3)
+    W = (0.1 * rs.standard_normal((5, 12))).astype(f32)
+    (tmp_path / "m.nnet").write_bytes(O.write_nnet([O.BiasedLinearity(W, np.zeros(5, f32)), O.Softmax(5)], True))
+    (tmp_path / "f.ark").write_bytes(O.write_matrix_ark([("u0", rs.standard_normal((20, 12)).astype(f32))]))
+    (tmp_path / "a.ark").write_bytes(O.write_int32_vector_ark([("u0", rs.randint(0, 5, 20).astype(np.int32))]))
+    _, err = run_tool(nn, "nnet-train-xent-hardlab-frmshuff", [
+        "--bunchsize=64", "--cachesize=128", "ark:" + str(tmp_path / "f.ark"), "ark:" + str(tmp_path / "a.ark"),
+        str(tmp_path / "m.nnet"), str(tmp_path / "out.nnet")])
+    assert re.findall(r"Cache #.*", err) == ["Cache #1 [RND] segments: 1 frames: 0"], err[-1500:]
+    out = [l for l in O.read_nnet((tmp_path / "out.nnet").read_bytes()) if isinstance(l, O.BiasedLinearity)][0]
+    np.testing.assert_allclose(out.W, W, rtol=2e-6)                   # nothing was trained (a text model: 7 digits)
+
+
 @pytest.mark.parametrize("queues", ["4", "8"])
 def test_train_tool_with_update_streams_and_few_hardware_queues(hip, nn, tmp_path, queues):
     """The configuration in which a training tool once never came back from synchronising its main stream at the second
