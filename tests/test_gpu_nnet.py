@@ -404,6 +404,27 @@ def test_train_tool_shuffles_a_last_cache_shorter_than_a_bunch(hip, nn, tmp_path
     np.testing.assert_allclose(out.W, W, rtol=2e-6)                   # nothing was trained (a text model: 7 digits)
 
 
+def test_train_tool_skips_missing_and_mis_sized_alignments(hip, nn, tmp_path):
+    """An utterance without an alignment is counted and skipped like the reference does
+    (nnetbin/nnet-train-xent-hardlab-frmshuff.cc:132-135).  One whose alignment has the wrong length is warned about,
+    counted under "other errors" and skipped as well: the reference means to (lines 139-144) but its `continue` sits
+    in front of the reader's Next(), so the reference tool itself never gets past such an utterance."""
+    rs = np.random.RandomState(4)
+    W = (0.1 * rs.standard_normal((5, 12))).astype(f32)
+    (tmp_path / "m.nnet").write_bytes(O.write_nnet([O.BiasedLinearity(W, np.zeros(5, f32)), O.Softmax(5)], True))
+    lens = [40, 30, 50, 20]
+    utts = [("u%d" % i, rs.standard_normal((n, 12)).astype(f32)) for i, n in enumerate(lens)]
+    alis = [("u0", rs.randint(0, 5, 40)), ("u1", rs.randint(0, 5, 31)), ("u3", rs.randint(0, 5, 20))]   # u1 too long, u2 absent
+    (tmp_path / "f.ark").write_bytes(O.write_matrix_ark(utts))
+    (tmp_path / "a.ark").write_bytes(O.write_int32_vector_ark([(k, v.astype(np.int32)) for k, v in alis]))
+    _, err = run_tool(nn, "nnet-train-xent-hardlab-frmshuff", [
+        "--bunchsize=20", "--cachesize=40", "--randomize=false", "ark:" + str(tmp_path / "f.ark"),
+        "ark:" + str(tmp_path / "a.ark"), str(tmp_path / "m.nnet"), str(tmp_path / "out.nnet")])
+    assert "Alignment has wrong size 31 vs. 30" in err
+    assert "Done 2 files, 1 with no alignments, 1 with other errors" in err, err[-1500:]
+    assert re.search(r"frames:60 ", err), err[-1500:]                       # u0 and u3, three whole bunches of 20
+
+
 @pytest.mark.parametrize("queues", ["4", "8"])
 def test_train_tool_with_update_streams_and_few_hardware_queues(hip, nn, tmp_path, queues):
     """The configuration in which a training tool once never came back from synchronising its main stream at the second
