@@ -156,6 +156,11 @@ int main(int argc, char *argv[]) {
       // (Like the reference, also a last cache that holds less than one bunch is shuffled -- its line says [RND] --
       // but a rank whose shard has run dry holds nothing to shuffle: it takes part in the collectives with 0 bunches.)
       if (!crossvalidate && randomize && fill_error.empty() && cache.HoldsRows()) cache.Randomize();
+      // Nothing to train on at all (an empty table, no utterance with an alignment): the reference stops in
+      // Cache::Randomize's assertion (nnet-cache.cc:141); a run that "succeeds" with a nan accuracy helps nobody.
+      // (A cache left empty BEHIND trained ones -- trailing utterances without alignments -- ends the run normally.)
+      if (dist.num_ranks == 1 && !crossvalidate && randomize && num_done == 0 && !cache.HoldsRows())
+        KALDI_ERR << "No utterance to train on: the feature table is empty or no utterance has an alignment";
       std::cerr << "Cache #" << ++num_cache << " " << (cache.Randomized() ? "[RND]" : "[NO-RND]")
                 << " segments: " << num_done << " frames: " << tot_t << "\n";
 

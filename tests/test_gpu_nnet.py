@@ -425,6 +425,24 @@ def test_train_tool_skips_missing_and_mis_sized_alignments(hip, nn, tmp_path):
     assert re.search(r"frames:60 ", err), err[-1500:]                       # u0 and u3, three whole bunches of 20
 
 
+def test_train_tool_refuses_a_table_with_nothing_to_train_on(hip, nn, tmp_path):
+    """An empty feature table, or one whose utterances all lack alignments: the reference stops in
+    Cache::Randomize's assertion (nnet-cache.cc:141) instead of reporting a nan accuracy; so does this tool
+    (with an error message).  Cross-validation of such a table ends normally in both."""
+    rs = np.random.RandomState(4)
+    W = (0.1 * rs.standard_normal((5, 12))).astype(f32)
+    (tmp_path / "m.nnet").write_bytes(O.write_nnet([O.BiasedLinearity(W, np.zeros(5, f32)), O.Softmax(5)], True))
+    (tmp_path / "empty.ark").write_bytes(b"")
+    (tmp_path / "f.ark").write_bytes(O.write_matrix_ark([("u0", rs.standard_normal((30, 12)).astype(f32))]))
+    (tmp_path / "a.ark").write_bytes(O.write_int32_vector_ark([("other", rs.randint(0, 5, 30).astype(np.int32))]))
+    for feats in ("empty.ark", "f.ark"):
+        args = ["--bunchsize=8", "--cachesize=16", "ark:" + str(tmp_path / feats), "ark:" + str(tmp_path / "a.ark"),
+                str(tmp_path / "m.nnet")]
+        _, err = run_tool(nn, "nnet-train-xent-hardlab-frmshuff", args + [str(tmp_path / "out.nnet")], expect_rc=255)
+        assert "No utterance to train on" in err and not (tmp_path / "out.nnet").exists()
+        run_tool(nn, "nnet-train-xent-hardlab-frmshuff", ["--cross-validate=true"] + args)
+
+
 @pytest.mark.parametrize("queues", ["4", "8"])
 def test_train_tool_with_update_streams_and_few_hardware_queues(hip, nn, tmp_path, queues):
     """The configuration in which a training tool once never came back from synchronising its main stream at the second

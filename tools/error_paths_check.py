@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""The tools of this build and of the reference (oracle/_ref/bin, CPU) on inputs that must fail -- wrong feature
+width, truncated archives and models, missing files, bad options, nothing to train on: both must refuse (non-zero
+exit status) or both succeed.  A diagnostic run on the GPU box.    python tools/error_paths_check.py"""
+import os, subprocess, sys, tempfile
+import numpy as np
+ROOT = "/root/repo" if os.path.exists("/root/repo/oracle") else os.getcwd()
+sys.path.insert(0, ROOT)
+from oracle import nnet1_oracle as O
+f32 = np.float32
+REF, OURS = os.path.join(ROOT, "oracle", "_ref", "bin"), os.path.join(ROOT, "kaldi_amd", "bin")
+tmp = tempfile.mkdtemp(prefix="errp_")
+rs = np.random.RandomState(5)
+layers = [O.BiasedLinearity((0.3 * rs.standard_normal((40, 24))).astype(f32), np.zeros(40, f32)), O.Sigmoid(40),
+          O.BiasedLinearity((0.3 * rs.standard_normal((11, 40))).astype(f32), np.zeros(11, f32)), O.Softmax(11)]
+model = O.write_nnet(layers, True)
+open(tmp + "/m.nnet", "wb").write(model)
+open(tmp + "/m_trunc.nnet", "wb").write(model[:len(model) // 2])
+open(tmp + "/m_text_trunc.nnet", "wb").write(O.write_nnet(layers, False)[:700])
+utts = [("utt%d" % i, rs.standard_normal((n, 24)).astype(f32)) for i, n in enumerate([5, 70, 33])]
+ark = O.write_matrix_ark(utts)
+open(tmp + "/f.ark", "wb").write(ark)
+open(tmp + "/f_trunc.ark", "wb").write(ark[:len(ark) - 100])
+open(tmp + "/f_wrongdim.ark", "wb").write(O.write_matrix_ark([("u", rs.standard_normal((9, 25)).astype(f32))]))
+open(tmp + "/empty.ark", "wb").write(b"")
+alis = [(k, rs.randint(0, 11, m.shape[0]).astype(np.int32)) for k, m in utts]
+open(tmp + "/a.ark", "wb").write(O.write_int32_vector_ark(alis))
+cases = [
+    ("forward wrong feature dim", "nnet-forward", [tmp + "/m.nnet", "ark:" + tmp + "/f_wrongdim.ark", "ark:/dev/null"]),
+    ("forward truncated archive", "nnet-forward", [tmp + "/m.nnet", "ark:" + tmp + "/f_trunc.ark", "ark:/dev/null"]),
+    ("forward truncated model", "nnet-forward", [tmp + "/m_trunc.nnet", "ark:" + tmp + "/f.ark", "ark:/dev/null"]),
+    ("forward truncated text model", "nnet-forward", [tmp + "/m_text_trunc.nnet", "ark:" + tmp + "/f.ark", "ark:/dev/null"]),
+    ("forward empty archive", "nnet-forward", [tmp + "/m.nnet", "ark:" + tmp + "/empty.ark", "ark:/dev/null"]),
+    ("forward missing archive", "nnet-forward", [tmp + "/m.nnet", "ark:" + tmp + "/nope.ark", "ark:/dev/null"]),
+    ("forward missing model", "nnet-forward", [tmp + "/nope.nnet", "ark:" + tmp + "/f.ark", "ark:/dev/null"]),
+    ("forward bad option", "nnet-forward", ["--nonsense=1", tmp + "/m.nnet", "ark:" + tmp + "/f.ark", "ark:/dev/null"]),
+    ("forward too few args", "nnet-forward", [tmp + "/m.nnet"]),
+    ("train wrong feature dim", "nnet-train-xent-hardlab-frmshuff", ["--bunchsize=4", "--cachesize=8", "ark:" + tmp + "/f_wrongdim.ark", "ark:" + tmp + "/a.ark", tmp + "/m.nnet", tmp + "/o.nnet"]),
+    ("train truncated archive", "nnet-train-xent-hardlab-frmshuff", ["--bunchsize=4", "--cachesize=8", "ark:" + tmp + "/f_trunc.ark", "ark:" + tmp + "/a.ark", tmp + "/m.nnet", tmp + "/o.nnet"]),
+    ("train empty archive", "nnet-train-xent-hardlab-frmshuff", ["--bunchsize=4", "--cachesize=8", "ark:" + tmp + "/empty.ark", "ark:" + tmp + "/a.ark", tmp + "/m.nnet", tmp + "/o.nnet"]),
+    ("train missing alignments file", "nnet-train-xent-hardlab-frmshuff", ["--bunchsize=4", "--cachesize=8", "ark:" + tmp + "/f.ark", "ark:" + tmp + "/nope.ark", tmp + "/m.nnet", tmp + "/o.nnet"]),
+    ("train cachesize < bunchsize", "nnet-train-xent-hardlab-frmshuff", ["--bunchsize=16", "--cachesize=8", "ark:" + tmp + "/f.ark", "ark:" + tmp + "/a.ark", tmp + "/m.nnet", tmp + "/o.nnet"]),
+    ("train unwritable output", "nnet-train-xent-hardlab-frmshuff", ["--bunchsize=4", "--cachesize=8", "ark:" + tmp + "/f.ark", "ark:" + tmp + "/a.ark", tmp + "/m.nnet", "/nonexistent_dir/o.nnet"]),
+]
+for name, tool, args in cases:
+    res = []
+    for d in (REF, OURS):
+        try:
+            r = subprocess.run([os.path.join(d, tool)] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=60)
+            res.append((r.returncode, r.stderr.decode(errors="replace").strip().splitlines()[-1:] ))
+        except subprocess.TimeoutExpired:
+            res.append(("timeout", []))
+    print("%-34s reference rc %-8s ours rc %-8s %s" % (name, res[0][0], res[1][0], "" if (res[0][0] == 0) == (res[1][0] == 0) else "<<< DIFFERENT"))
+    if (res[0][0] == 0) != (res[1][0] == 0):
+        print("    ref :", res[0][1]); print("    ours:", res[1][1])
