@@ -244,6 +244,30 @@ def sibling_case(rs, tmp, c, tool):
     return None if cv else _compare_models(outs["ref"][2], outs["ours"][2], opts)
 
 
+def copy_case(rs, tmp, c):
+    """nnet-copy (text <-> binary) of the case's model and rbm-convert-to-nnet of a random RBM: the written files
+    must be the reference's byte for byte."""
+    vis, hid = int(rs.choice([13, 40, 333])), int(rs.choice([17, 256, 100]))
+    rbm = O.Rbm((0.1 * rs.standard_normal((hid, vis))).astype(f32), (0.1 * rs.standard_normal(vis)).astype(f32),
+                (0.1 * rs.standard_normal(hid)).astype(f32), str(rs.choice(["bern", "gauss"])), "bern")
+    open(os.path.join(tmp, "r.rbm"), "wb").write(O.write_nnet([rbm], bool(rs.rand() < 0.5)))
+    jobs = []
+    for binary in ("true", "false"):
+        jobs.append(("nnet-copy", ["--binary=" + binary, os.path.join(tmp, "m.nnet")], "copy_%s" % binary))
+        jobs.append(("rbm-convert-to-nnet", ["--binary=" + binary, os.path.join(tmp, "r.rbm")], "conv_%s" % binary))
+    for tool, args, tag in jobs:
+        out = {}
+        for who, d in (("ref", REF), ("ours", OURS)):
+            path = os.path.join(tmp, "%s_%s.out" % (tag, who))
+            rc, err = run(os.path.join(d, tool), args + [path])
+            out[who] = (rc, open(path, "rb").read() if rc == 0 and os.path.exists(path) else None, err)
+        if out["ref"][0] != out["ours"][0]:
+            return "%s %s: exit codes differ: %d %d\n%s" % (tool, args[0], out["ref"][0], out["ours"][0], out["ours"][2][-600:])
+        if out["ref"][1] != out["ours"][1]:
+            return "%s %s: files differ (%d / %d bytes)" % (tool, args[0], len(out["ref"][1] or b""), len(out["ours"][1] or b""))
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=40)
@@ -251,7 +275,7 @@ def main():
     ap.add_argument("--keep", default="")
     ap.add_argument("--exotic", action="store_true", help="also <relu> / <softrelu> / <scale> layers, text alignment "
                     "archives, utterances without or with mis-sized alignments")
-    ap.add_argument("--siblings", action="store_true", help="also nnet-train-xent-hardlab-perutt and nnet-train-mse-tgtmat-frmshuff")
+    ap.add_argument("--siblings", action="store_true", help="also nnet-train-xent-hardlab-perutt, nnet-train-mse-tgtmat-frmshuff, nnet-copy and rbm-convert-to-nnet")
     args = ap.parse_args()
     for t in ("nnet-forward", "nnet-train-xent-hardlab-frmshuff"):
         for d in (REF, OURS):
@@ -262,11 +286,13 @@ def main():
         rs = np.random.RandomState(args.seed * 1000 + i)
         tmp = tempfile.mkdtemp(prefix="diff_fuzz_")
         c = make_case(rs, tmp, args.exotic)
-        kind = ("forward", "train", "perutt", "mse")[i % 4] if args.siblings else ("forward", "train")[i % 2]
+        kind = ("forward", "train", "perutt", "mse", "copy")[i % 5] if args.siblings else ("forward", "train")[i % 2]
         if kind == "forward":
             msg = forward_case(rs, tmp, c)
         elif kind == "train":
             msg = train_case(rs, tmp, c)
+        elif kind == "copy":
+            msg = copy_case(rs, tmp, c)
         else:
             msg = sibling_case(rs, tmp, c, "nnet-train-xent-hardlab-perutt" if kind == "perutt" else "nnet-train-mse-tgtmat-frmshuff")
         print("case %d (%s, dims %s, %d utterances, %s model): %s" % (
