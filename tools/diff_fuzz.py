@@ -35,7 +35,22 @@ def make_case(rs, tmp, exotic=False):
     splice = rs.rand() < 0.35 and in_dim <= 40
     hidden = [int(rs.choice([17, 32, 100, 256, 333, 1024])) for _ in range(rs.randint(0, 4))]
     out_dim = int(rs.choice([9, 50, 201, 1483]))
-    net_in = in_dim * 5 if splice else in_dim
+    # feature transform: a splice, then perhaps a column selection, then perhaps an affine map (as the recipes' global
+    # normalisation / LDA transforms are)
+    tlayers, net_in = [], in_dim
+    if splice:
+        ctx = int(rs.choice([1, 2, 5]))
+        tlayers.append(O.Expand(in_dim, in_dim * (2 * ctx + 1), list(range(-ctx, ctx + 1))))
+        net_in = in_dim * (2 * ctx + 1)
+        if exotic and rs.rand() < 0.5:
+            keep = rs.permutation(net_in)[:max(3, net_in // 2)]
+            tlayers.append(O.Copy(net_in, len(keep), [int(k) for k in keep]))
+            net_in = len(keep)
+        if exotic and rs.rand() < 0.4:
+            out = int(rs.choice([net_in, 24, 60]))
+            tlayers.append(O.BiasedLinearity((rs.standard_normal((out, net_in)) / np.sqrt(net_in)).astype(f32),
+                                             (0.1 * rs.standard_normal(out)).astype(f32)))
+            net_in = out
     dims = [net_in] + hidden + [out_dim]
     layers = []
     for i in range(len(dims) - 1):
@@ -61,7 +76,7 @@ def make_case(rs, tmp, exotic=False):
     transform = None
     if splice:
         transform = os.path.join(tmp, "t.nnet")
-        open(transform, "wb").write(O.write_nnet([O.Expand(in_dim, net_in, [-2, -1, 0, 1, 2])], binary))
+        open(transform, "wb").write(O.write_nnet(tlayers, binary))
     n_utts = rs.randint(1, 10)
     lens = [int(rs.choice([1, 2, 7, 64, 130, 300, 700])) for _ in range(n_utts)]
     utts = [("utt%03d" % i, rs.standard_normal((n, in_dim)).astype(f32)) for i, n in enumerate(lens)]
