@@ -32,8 +32,9 @@ int static_scratch_setup(int device) {
 
 namespace {
 
-// 16-byte buffer accesses to a row of floats: the descriptor ends with the row's last whole group of 4 columns, so
-// lanes past the end read 0 and write nothing, without a branch around the access.
+// 16-byte buffer loads from a row of floats: the descriptor ends with the group of 4 that holds the row's last column,
+// so lanes past the end read 0 without a branch around the access (a ragged last group reads up to 3 floats of the row's
+// pitch behind the last column; the kernels mask them out).
 typedef int kh_v4i __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t row_rsrc(const float *p, int cols) {
   return __builtin_amdgcn_make_buffer_rsrc((void *)p, 0, ((cols + 3) & ~3) * 4, 0x00020000);
@@ -42,9 +43,29 @@ __device__ __forceinline__ float4 row_load4(__amdgpu_buffer_rsrc_t rs, int c) {
   const kh_v4i r = __builtin_amdgcn_raw_buffer_load_b128(rs, c * 4, 0, 0);
   return make_float4(__int_as_float(r.x), __int_as_float(r.y), __int_as_float(r.z), __int_as_float(r.w));
 }
-__device__ __forceinline__ void row_store4(__amdgpu_buffer_rsrc_t rs, int c, float a, float b, float cc, float d) {
+// Stores to a row write the row's columns and nothing else -- a caller's matrix may be a window of a larger one, whose
+// row pitch then holds live data behind the last column.  Whole groups of 4 go out as one 16-byte access bounded by a
+// descriptor that ends with the last whole group; the lane that holds a ragged last group (a row length that is not a
+// multiple of 4) writes its columns one by one.
+struct RowOut {
+  __amdgpu_buffer_rsrc_t whole, exact;
+  int cols;
+};
+__device__ __forceinline__ RowOut row_out(float *p, int cols) {
+  RowOut o;
+  o.whole = __builtin_amdgcn_make_buffer_rsrc((void *)p, 0, (cols & ~3) * 4, 0x00020000);
+  o.exact = __builtin_amdgcn_make_buffer_rsrc((void *)p, 0, cols * 4, 0x00020000);
+  o.cols = cols;
+  return o;
+}
+__device__ __forceinline__ void row_store4(const RowOut &o, int c, float a, float b, float cc, float d) {
   kh_v4i v = {__float_as_int(a), __float_as_int(b), __float_as_int(cc), __float_as_int(d)};
-  __builtin_amdgcn_raw_buffer_store_b128(v, rs, c * 4, 0, 0);
+  __builtin_amdgcn_raw_buffer_store_b128(v, o.whole, c * 4, 0, 0);
+  if (c < o.cols && c + 4 > o.cols) {  // (at most one lane of a row, and none when the length is a multiple of 4)
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(a), o.exact, c * 4, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(b), o.exact, c * 4 + 4, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(cc), o.exact, c * 4 + 8, 0, 0);
+  }
 }
 // ---- vec[c] = alpha * sum_r mat[r,c] + beta * vec[c] ---------------------------------------
 // Block = 64 columns x 16 row groups; lane -> column keeps every wave load a contiguous 256 B.
@@ -304,7 +325,7 @@ __global__ __launch_bounds__(kSoftmaxThreads) void softmax_vec_kernel(float *y, 
   float *py = y + (size_t)r * ldy;
   float4 v[NV];
   const float inv = softmax_row_regs<NV>(v, x + (size_t)r * ldx, nslab, slab_stride, bias, cols, red);
-  const __amdgpu_buffer_rsrc_t rsy = row_rsrc(py, cols);
+  const RowOut rsy = row_out(py, cols);
 #pragma unroll
   for (int k = 0; k < NV; ++k)
     row_store4(rsy, (threadIdx.x + k * kSoftmaxThreads) * 4, v[k].x * inv, v[k].y * inv, v[k].z * inv, v[k].w * inv);
@@ -384,7 +405,7 @@ __global__ __launch_bounds__(256) void softmax_wave_kernel(float *y, int ldy, co
   if (r >= rows) return;
   float4 v[NV];
   const float inv = softmax_row_wave<NV>(v, x + (size_t)r * ldx, nslab, slab_stride, bias, cols);
-  const __amdgpu_buffer_rsrc_t rsy = row_rsrc(y + (size_t)r * ldy, cols);
+  const RowOut rsy = row_out(y + (size_t)r * ldy, cols);
 #pragma unroll
   for (int k = 0; k < NV; ++k) row_store4(rsy, (lane + k * 64) * 4, v[k].x * inv, v[k].y * inv, v[k].z * inv, v[k].w * inv);
 }
@@ -711,7 +732,7 @@ __global__ __launch_bounds__(256) void xent_rows_wave_kernel(const float *post, 
     const int t = tgt[r];
     const bool t_ok = (t >= 0 && t < d.cols);
     const __amdgpu_buffer_rsrc_t rs = row_rsrc(post + (size_t)r * d.stride, d.cols);
-    const __amdgpu_buffer_rsrc_t rq = row_rsrc(diff + (size_t)r * d.stride, d.cols);
+    const RowOut rq = row_out(diff + (size_t)r * d.stride, d.cols);
     float4 v[NV];
 #pragma unroll
     for (int k = 0; k < NV; ++k) v[k] = row_load4(rs, (lane + k * 64) * 4);
@@ -786,8 +807,8 @@ __global__ __launch_bounds__(kSoftmaxThreads) void softmax_xent_vec_kernel(float
   const float inv = softmax_row_regs<NV>(v, x + (size_t)r * ldx, nslab, slab_stride, bias, cols, red);
   const int t = xf.tgt[r];
   const bool t_ok = (t >= 0 && t < cols);
-  const __amdgpu_buffer_rsrc_t rsy = row_rsrc(y + (size_t)r * ldy, xf.write_post ? cols : 0);  // 0 columns: nothing is written
-  const __amdgpu_buffer_rsrc_t rsd = row_rsrc(xf.diff + (size_t)r * xf.lddiff, cols);
+  const RowOut rsy = row_out(y + (size_t)r * ldy, xf.write_post ? cols : 0);  // 0 columns: nothing is written
+  const RowOut rsd = row_out(xf.diff + (size_t)r * xf.lddiff, cols);
   // Order of the rest: arg-max and target posterior first (registers only), the row's results and this
   // workgroup's arrival next, the row stores after that -- so the write acknowledgement and the counter's round
   // trip (two trips to the memory side) pass while the 2 x 36 KB of the row are being stored, not after them --
@@ -874,8 +895,8 @@ __global__ __launch_bounds__(256) void softmax_xent_wave_kernel(float *y, int ld
     const float inv = softmax_row_wave<NV>(v, x + (size_t)r * ldx, nslab, slab_stride, bias, cols);
     const int t = xf.tgt[r];
     const bool t_ok = (t >= 0 && t < cols);
-    const __amdgpu_buffer_rsrc_t rsy = row_rsrc(y + (size_t)r * ldy, xf.write_post ? cols : 0);  // 0 columns: nothing is written
-    const __amdgpu_buffer_rsrc_t rsd = row_rsrc(xf.diff + (size_t)r * xf.lddiff, cols);
+    const RowOut rsy = row_out(y + (size_t)r * ldy, xf.write_post ? cols : 0);  // 0 columns: nothing is written
+    const RowOut rsd = row_out(xf.diff + (size_t)r * xf.lddiff, cols);
     MaxId m;
     m.v = -1e21f;
     m.i = -1;

@@ -351,6 +351,64 @@ def test_cache_sized_streaming_kernels(hip):
     close(ds.numpy(), O.sigmoid(x))
 
 
+@pytest.mark.parametrize("rows,cols", [(58, 209), (1, 1), (300, 1), (1500, 255), (20, 1941), (40, 9001)])
+def test_row_kernels_write_their_window_only(hip, rows, cols):
+    """softmax, xent_eval and the fused output layer on a WINDOW of a larger buffer whose row length is not a multiple
+    of 4: the columns behind the window's last one belong to somebody else and must come back untouched (the
+    16-byte row stores once ran to the end of the last group of 4) -- found by tools/op_fuzz.py."""
+    import ctypes
+    h = hip
+    rs = np.random.RandomState(31)
+    FILL = f32(-777.25)
+    c0, pad = 4, 7
+    S = c0 + cols + pad
+    S += (-S) % 4                                       # 16-byte row pitch, so the 16-byte paths are taken
+    x = (2 * rs.standard_normal((rows, cols))).astype(f32)
+
+    def window(data=None):
+        host = np.full((rows + 2, S), FILL, f32)
+        if data is not None:
+            host[1:1 + rows, c0:c0 + cols] = data
+        d = h.DevMatrix.from_numpy(host, pitched=False)
+        return d, ctypes.c_void_p(d.ptr.value + 4 * (S + c0))
+
+    def outside_untouched(d):
+        got = d.numpy().copy()
+        win = got[1:1 + rows, c0:c0 + cols].copy()
+        got[1:1 + rows, c0:c0 + cols] = FILL
+        assert (got == FILL).all(), np.argwhere(got != FILL)[:4]
+        return win
+
+    dim = h.MatrixDim(rows, cols, S)
+    dx, px = window(x)
+    dy, py = window()
+    h.call("hipF_softmax", None, py, px, dim)
+    p = O.softmax(x)
+    close(outside_untouched(dy), p, 1e-4, 1e-7)
+    tgt = rs.randint(0, cols, rows).astype(np.int32)
+    dp, pp = window(p)
+    dq, pq = window()
+    cnt, loss = h.DevMatrix(1, 2, np.int64, pitched=False), h.DevMatrix(1, 1, np.float64, pitched=False)
+    h.call("hipF_xent_eval", None, pp, dev(h, tgt, False).ptr, pq, None, None, cnt.ptr, loss.ptr, dim)
+    want = p.copy()
+    want[np.arange(rows), tgt] -= 1
+    close(outside_untouched(dq), want, 1e-6, 1e-7)
+    if cols <= 2100:
+        I = 24
+        W, b = (0.3 * rs.standard_normal((cols, I))).astype(f32), (0.1 * rs.standard_normal(cols)).astype(f32)
+        xin = rs.standard_normal((rows, I)).astype(f32)
+        dpo, ppo = window()
+        ddi, pdi = window()
+        dW, din = dev(h, W), dev(h, xin)
+        h.call("hipF_affine_forward_xent", None, 112, rows, cols, I, din.ptr, din.stride, dW.ptr, dW.stride, dev(h, b, False).ptr,
+               ppo, S, 1, dev(h, tgt, False).ptr, pdi, S, None, None, cnt.ptr, loss.ptr)
+        pr = O.softmax((xin.astype(np.float64) @ W.T.astype(np.float64) + b).astype(f32))
+        close(outside_untouched(dpo), pr, 2e-4, 1e-7)
+        wd = pr.copy()
+        wd[np.arange(rows), tgt] -= 1
+        close(outside_untouched(ddi), wd, 2e-4, 2e-6)
+
+
 def test_hybrid_taus_bit_exact_vs_oracle_parity_unpinned(hip):
     """HybridTaus streams against the oracle's restatement of cu-randkernels.cu:44-94, bit for bit.  Parity unpinned:
     the reference holds no vector for its generator and its kernels need nvcc, so nothing it produced can be compared."""
