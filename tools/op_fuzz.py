@@ -91,7 +91,8 @@ def one_case(rs):
     aligned = rs.rand() < 0.4
     op = rs.choice(["sigmoid", "diff_sigmoid", "add_mat", "scale", "mul_elements", "add_vec_to_rows", "softmax", "find_row_max_id",
                     "add_row_sum_mat", "add_col_sum_mat", "randomize", "gemm", "xent_eval", "affine_forward", "affine_backward",
-                    "affine_update", "affine_forward_xent"])
+                    "affine_update", "affine_forward_xent", "unary", "vec_scale", "part_ops", "l2bound", "l1", "diff_xent",
+                    "expand", "copy", "mse_eval", "nonfinite", "relu_family", "softmax_part"])
     x = rs.standard_normal((rows, cols)).astype(f32)
     tag = "%s %dx%d%s" % (op, rows, cols, " aligned" if aligned else "")
     if op == "sigmoid":
@@ -181,6 +182,134 @@ def one_case(rs):
         want = al * ((A.T if ta else A).astype(np.float64) @ (B.T if tb else B).astype(np.float64)) + be * C0
         tag = "gemm %s%s %dx%dx%d%s" % ("T" if ta else "N", "T" if tb else "N", M, N, K, " aligned" if aligned else "")
         return tag, wc.check(want.astype(f32), 1e-4, 1e-4 * np.sqrt(K), "gemm")
+    if op == "unary":
+        which = rs.choice(["set_const", "binarize", "add_const", "apply_floor", "apply_truncate", "apply_exp", "apply_log", "invert_elements", "round"])
+        data = np.abs(x) + f32(0.5) if which in ("apply_log", "invert_elements") else x
+        a = Window(rs, rows, cols, data, aligned)
+        args = {"set_const": (f32(2.5),), "binarize": (f32(0.1),), "add_const": (f32(-1.5),), "apply_floor": (f32(0.2),),
+                "apply_truncate": (f32(-0.3), f32(0.4)), "apply_exp": (), "apply_log": (), "invert_elements": (), "round": ()}[which]
+        h.call("hipF_" + which, None, a.ptr, *args, a.dim)
+        want = {"set_const": lambda: np.full_like(x, 2.5), "binarize": lambda: (x > f32(0.1)).astype(f32), "add_const": lambda: x - f32(1.5),
+                "apply_floor": lambda: np.maximum(x, f32(0.2)), "apply_truncate": lambda: np.clip(x, f32(-0.3), f32(0.4)),
+                "apply_exp": lambda: np.exp(x), "apply_log": lambda: np.log(data), "invert_elements": lambda: f32(1) / data,
+                "round": lambda: np.where(x >= 0, np.floor(x + f32(0.5)), np.ceil(x - f32(0.5)))}[which]()
+        return tag + " " + which, a.check(want.astype(f32), 2e-6, 2e-6, which)
+    if op == "vec_scale":
+        which = rs.choice(["mul_cols_vec", "mul_rows_vec", "div_cols_vec", "div_rows_vec", "add_vec_to_cols"])
+        a = Window(rs, rows, cols, x, aligned)
+        per_col = which in ("mul_cols_vec", "div_cols_vec")
+        v = (np.abs(rs.standard_normal(cols if per_col else rows)) + 0.5).astype(f32)
+        dv = h.DevMatrix.from_numpy(v, pitched=False)
+        vb = v[None, :] if per_col else v[:, None]
+        if which == "add_vec_to_cols":
+            h.call("hipF_add_vec_to_cols", None, f32(0.5), dv.ptr, f32(1.0), a.ptr, a.dim)
+            want = f32(0.5) * vb + x
+        else:
+            h.call("hipF_" + which, None, a.ptr, dv.ptr, a.dim)
+            want = x * vb if which.startswith("mul") else x * (f32(1) / vb)
+        return tag + " " + which, a.check(want.astype(f32), 2e-6, 2e-6, which)
+    if op == "part_ops":
+        a = Window(rs, rows, cols, x, aligned)
+        r, c = int(rs.randint(1, rows + 1)), int(rs.randint(1, cols + 1))
+        ro, co = int(rs.randint(0, rows - r + 1)), int(rs.randint(0, cols - c + 1))
+        want = x.copy()
+        if rs.rand() < 0.5:
+            h.call("hipF_part_set_const", None, a.ptr, f32(3.0), a.dim, ro, r, co, c)
+            want[ro:ro + r, co:co + c] = 3.0
+            return tag + " part_set_const", a.check(want, 0, 0, "part_set_const")
+        row = rs.standard_normal(c).astype(f32)
+        dr = h.DevMatrix.from_numpy(row, pitched=False)
+        h.call("hipF_add_vec_to_partial_rows", None, f32(2.0), co, dr.ptr, c, f32(1.0), a.ptr, a.dim)
+        want[:, co:co + c] += f32(2.0) * row[None, :]
+        return tag + " add_vec_to_partial_rows", a.check(want, 2e-6, 2e-6, "add_vec_to_partial_rows")
+    if op == "l2bound":
+        a = Window(rs, rows, cols, x, aligned)
+        bound = f32(0.7 * np.sqrt(cols))
+        h.call("hipF_apply_row_l2upperbound", None, a.ptr, bound, a.dim)
+        return tag, a.check(O.apply_row_l2_upper_bound(x.copy(), bound), 2e-5, 2e-6, op)
+    if op == "l1":
+        g0 = rs.standard_normal((rows, cols)).astype(f32)
+        w0 = (0.01 * x).astype(f32)
+        w, g = Window(rs, rows, cols, w0, aligned), None
+        g = w.like(rs, g0)
+        l1, lr = f32(0.02), f32(0.1)
+        h.call("hipF_regularize_l1", None, w.ptr, g.ptr, l1, lr, w.dim)
+        ww, gg = O.regularize_l1(w0.copy(), g0.copy(), l1, lr)
+        return tag, w.check(ww, 2e-6, 1e-7, op + " (weights)") or g.check(gg, 2e-6, 1e-7, op + " (gradient)")
+    if op == "diff_xent":
+        p = O.softmax(2 * x)
+        tgt = rs.randint(0, cols, rows).astype(np.int32)
+        a = Window(rs, rows, cols, p, aligned)
+        lp = h.DevMatrix(1, rows, f32, pitched=False)
+        h.call("hipF_diff_xent", None, h.DevMatrix.from_numpy(tgt, pitched=False).ptr, a.ptr, lp.ptr, a.dim)
+        want, wlp = O.diff_xent(tgt, p.copy())
+        msg = a.check(want, 1e-6, 1e-7, op)
+        if msg is None and not np.allclose(lp.numpy()[0], wlp, rtol=1e-5, atol=1e-6):
+            msg = "log posteriors differ"
+        return tag, msg
+    if op == "expand":
+        cols_in = max(1, min(cols, 60))
+        xin = rs.standard_normal((rows, cols_in)).astype(f32)
+        offs = rs.randint(-7, 8, int(rs.randint(1, 12))).astype(np.int32)
+        a = Window(rs, rows, cols_in, xin, aligned)
+        y = Window(rs, rows, cols_in * len(offs), None, aligned)
+        h.call("hipF_expand", None, y.ptr, a.ptr, h.DevMatrix.from_numpy(offs, pitched=False).ptr, y.dim, a.dim)
+        return tag + " x%d" % len(offs), y.check(O.expand(xin, offs), 0, 0, op)
+    if op == "copy":
+        n_out = int(rs.randint(1, 2 * cols + 2))
+        idx = rs.randint(0, cols, n_out).astype(np.int32)
+        a = Window(rs, rows, cols, x, aligned)
+        y = Window(rs, rows, n_out, None, aligned)
+        h.call("hipF_copy", None, y.ptr, a.ptr, h.DevMatrix.from_numpy(idx, pitched=False).ptr, y.dim, a.dim)
+        return tag, y.check(x[:, idx], 0, 0, op)
+    if op == "mse_eval":
+        b0 = rs.standard_normal((rows, cols)).astype(f32)
+        a = Window(rs, rows, cols, x, aligned)
+        b = a.like(rs, b0)
+        dd = a.like(rs)
+        rowsq, loss = h.DevMatrix(1, rows, f32, pitched=False), h.DevMatrix(1, 1, np.float64, pitched=False)
+        h.call("hipF_mse_eval", None, a.ptr, b.ptr, dd.ptr, rowsq.ptr, loss.ptr, a.dim)
+        rdiff, rrow, rloss = O.mse_eval(x, b0)
+        msg = dd.check(rdiff, 1e-6, 1e-6, op)
+        if msg is None and abs(loss.numpy()[0, 0] - rloss) > 1e-5 * max(rloss, 1e-3):
+            msg = "loss %.8g want %.8g" % (loss.numpy()[0, 0], rloss)
+        return tag, msg
+    if op == "nonfinite":
+        n_nan, n_inf = int(rs.randint(0, 4)), int(rs.randint(0, 4))
+        flat = x.reshape(-1)
+        pos = rs.permutation(flat.size)[:n_nan + n_inf]
+        flat[pos[:n_nan]] = np.nan
+        flat[pos[n_nan:]] = np.inf
+        a = Window(rs, rows, cols, x, aligned)
+        cnt = h.DevMatrix(1, 2, np.int32, pitched=False)
+        h.call("hipF_count_nonfinite", None, a.ptr, a.dim, cnt.ptr)
+        want = [int(np.isnan(x).sum()), int(np.isposinf(x).sum())]
+        return tag, None if cnt.numpy()[0].tolist() == want else "counts %s want %s" % (cnt.numpy()[0].tolist(), want)
+    if op == "relu_family":
+        which = rs.choice(["relu", "softrelu", "diff_relu", "diff_softrelu"])
+        a = Window(rs, rows, cols, 3 * x, aligned)
+        y = a.like(rs)
+        if which == "relu":
+            h.call("hipF_relu", None, y.ptr, a.ptr, a.dim)
+            want = O.Relu(cols).propagate(3 * x)
+        elif which == "softrelu":
+            h.call("hipF_softrelu", None, y.ptr, a.ptr, a.dim)
+            want = O.SoftRelu(cols).propagate(3 * x)
+        else:
+            e0 = rs.standard_normal((rows, cols)).astype(f32)
+            e = a.like(rs, e0)
+            h.call("hipF_" + which, None, y.ptr, e.ptr, a.ptr, a.dim)
+            want = (O.Relu(cols).backpropagate(e0, y_out=np.maximum(3 * x, 0)) if which == "diff_relu"
+                    else O.SoftRelu(cols).backpropagate(e0, y_in=3 * x))
+            if which == "diff_relu":   # the entry point takes the layer's output y; a holds 3x here, same sign pattern
+                want = (e0 * ((3 * x) > 0)).astype(f32)
+        return tag + " " + which, y.check(want, 2e-5, 2e-6, which)
+    if op == "softmax_part":
+        ids = x.argmax(axis=1).astype(np.int32)
+        a = Window(rs, rows, cols, x, aligned)
+        y = a.like(rs)
+        h.call("hipF_softmax_part", None, a.ptr, h.DevMatrix.from_numpy(ids, pitched=False).ptr, y.ptr, a.dim)
+        return tag, y.check(np.exp(x - x[np.arange(rows), ids][:, None]), 2e-6, 1e-7, op)
     if op == "xent_eval":
         p = O.softmax(2 * x)
         tgt = rs.randint(0, cols, rows).astype(np.int32)
