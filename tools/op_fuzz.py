@@ -92,7 +92,7 @@ def one_case(rs):
     op = rs.choice(["sigmoid", "diff_sigmoid", "add_mat", "scale", "mul_elements", "add_vec_to_rows", "softmax", "find_row_max_id",
                     "add_row_sum_mat", "add_col_sum_mat", "randomize", "gemm", "xent_eval", "affine_forward", "affine_backward",
                     "affine_update", "affine_forward_xent", "unary", "vec_scale", "part_ops", "l2bound", "l1", "diff_xent",
-                    "expand", "copy", "mse_eval", "nonfinite", "relu_family", "softmax_part"])
+                    "expand", "copy", "mse_eval", "nonfinite", "relu_family", "softmax_part", "rbm_update", "rbm_update"])
     x = rs.standard_normal((rows, cols)).astype(f32)
     tag = "%s %dx%d%s" % (op, rows, cols, " aligned" if aligned else "")
     if op == "sigmoid":
@@ -310,6 +310,44 @@ def one_case(rs):
         y = a.like(rs)
         h.call("hipF_softmax_part", None, a.ptr, h.DevMatrix.from_numpy(ids, pitched=False).ptr, y.ptr, a.dim)
         return tag, y.check(np.exp(x - x[np.arange(rows), ids][:, None]), 2e-6, 1e-7, op)
+    if op == "rbm_update":
+        N, H, V = int(rs.choice([1, 7, 64, 256])), int(rs.randint(1, 500)), int(rs.randint(1, 500))
+        if rs.rand() < 0.3:
+            H, V = int(rs.choice([1024, 2048])), int(rs.choice([440, 2048]))
+        tag = "rbm_update N=%d H=%d V=%d%s" % (N, H, V, " aligned" if aligned else "")
+        rbm = O.Rbm((0.1 * rs.standard_normal((H, V))).astype(f32), (0.1 * rs.standard_normal(V)).astype(f32), (0.1 * rs.standard_normal(H)).astype(f32))
+        rbm.W_corr = (0.01 * rs.standard_normal((H, V))).astype(f32)
+        rbm.vis_bias_corr = (0.01 * rs.standard_normal(V)).astype(f32)
+        rbm.hid_bias_corr = (0.01 * rs.standard_normal(H)).astype(f32)
+        rbm.learn_rate, rbm.momentum, rbm.l2_penalty = f32(0.05), f32(rs.choice([0.0, 0.5])), f32(rs.choice([0.0, 2e-3]))
+        pv, nv = rs.random_sample((N, V)).astype(f32), rs.random_sample((N, V)).astype(f32)
+        ph, nh = rs.random_sample((N, H)).astype(f32), rs.random_sample((N, H)).astype(f32)
+        wpv, wnv = Window(rs, N, V, pv, aligned), None
+        wnv = wpv.like(rs, nv)                      # (the fused error needs one pitch for the two visible matrices)
+        wph, wnh = Window(rs, N, H, ph, aligned), Window(rs, N, H, nh, aligned)
+        wW, wdW = Window(rs, H, V, rbm.W, aligned), Window(rs, H, V, rbm.W_corr, aligned)
+        dvb, ddvb = h.DevMatrix.from_numpy(rbm.vis_bias, pitched=False), h.DevMatrix.from_numpy(rbm.vis_bias_corr, pitched=False)
+        dhb, ddhb = h.DevMatrix.from_numpy(rbm.hid_bias, pitched=False), h.DevMatrix.from_numpy(rbm.hid_bias_corr, pitched=False)
+        args = [None, N, H, V, wpv.ptr, wpv.S, wph.ptr, wph.S, wnv.ptr, wnv.S, wnh.ptr, wnh.S, rbm.learn_rate, rbm.momentum, rbm.l2_penalty,
+                wW.ptr, wW.S, wdW.ptr, wdW.S, dvb.ptr, ddvb.ptr, dhb.ptr, ddhb.ptr]
+        with_mse = rs.rand() < 0.5
+        if with_mse:
+            loss = h.DevMatrix(1, 1, np.float64, pitched=False)
+            h.call("hipF_rbm_update_mse", *args, loss.ptr)
+        else:
+            h.call("hipF_rbm_update", *args)
+        rbm.rbm_update(pv, ph, nv, nh)
+        msg = (wW.check(rbm.W, 2e-4, 2e-6, "rbm (W)") or wdW.check(rbm.W_corr, 2e-4, 2e-6, "rbm (dW)") or
+               wpv.check(pv, 0, 0, "rbm (pos_vis)") or wnh.check(nh, 0, 0, "rbm (neg_hid)"))
+        for name, d, want in (("vis_bias", dvb, rbm.vis_bias), ("dvis_bias", ddvb, rbm.vis_bias_corr), ("hid_bias", dhb, rbm.hid_bias),
+                              ("dhid_bias", ddhb, rbm.hid_bias_corr)):
+            if msg is None and not np.allclose(d.numpy()[0], want, rtol=2e-4, atol=2e-6):
+                msg = "%s differs: max abs %.3g" % (name, np.abs(d.numpy()[0] - want).max())
+        if msg is None and with_mse:
+            want = 0.5 * ((nv.astype(np.float64) - pv) ** 2).sum()
+            if abs(loss.numpy()[0, 0] - want) > 1e-5 * max(want, 1e-3):
+                msg = "reconstruction error %.8g want %.8g" % (loss.numpy()[0, 0], want)
+        return tag + (" +mse" if with_mse else ""), msg
     if op == "xent_eval":
         p = O.softmax(2 * x)
         tgt = rs.randint(0, cols, rows).astype(np.int32)
