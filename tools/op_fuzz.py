@@ -92,7 +92,7 @@ def one_case(rs):
     op = rs.choice(["sigmoid", "diff_sigmoid", "add_mat", "scale", "mul_elements", "add_vec_to_rows", "softmax", "find_row_max_id",
                     "add_row_sum_mat", "add_col_sum_mat", "randomize", "gemm", "xent_eval", "affine_forward", "affine_backward",
                     "affine_update", "affine_forward_xent", "unary", "vec_scale", "part_ops", "l2bound", "l1", "diff_xent",
-                    "expand", "copy", "mse_eval", "nonfinite", "relu_family", "softmax_part", "rbm_update", "rbm_update"])
+                    "expand", "copy", "mse_eval", "nonfinite", "relu_family", "softmax_part", "rbm_update", "rbm_update", "rng"])
     x = rs.standard_normal((rows, cols)).astype(f32)
     tag = "%s %dx%d%s" % (op, rows, cols, " aligned" if aligned else "")
     if op == "sigmoid":
@@ -310,6 +310,37 @@ def one_case(rs):
         y = a.like(rs)
         h.call("hipF_softmax_part", None, a.ptr, h.DevMatrix.from_numpy(ids, pitched=False).ptr, y.ptr, a.dim)
         return tag, y.check(np.exp(x - x[np.arange(rows), ids][:, None]), 2e-6, 1e-7, op)
+    if op == "rng":
+        rows, cols = min(rows, 300), min(cols, 700)     # (the oracle's generator is numpy code over whole arrays)
+        which = rs.choice(["rand", "binarize_probs_rand", "add_gauss_noise"])
+        probs = rs.random_sample((rows, cols)).astype(f32)
+        a = Window(rs, rows, cols, probs, aligned)
+        out = a.like(rs, probs)
+        # generator states laid out like the window's buffer: one state per buffer element
+        zs = [rs.randint(128, 2 ** 31 - 1, (a.R, a.S)).astype(np.uint32) for _ in range(4)]
+        dz = [h.DevMatrix.from_numpy(z, pitched=False) for z in zs]
+        zp = [ctypes.c_void_p(d.ptr.value + 4 * (a.r0 * a.S + a.c0)) for d in dz]
+        zwin = [z[a.r0:a.r0 + rows, a.c0:a.c0 + cols] for z in zs]
+        tag = "%s %dx%d%s" % (which, rows, cols, " aligned" if aligned else "")
+        if which == "rand":
+            h.call("hipF_rand", None, out.ptr, *zp, a.dim)
+            u, znew = O.hybrid_taus(*zwin)
+            msg = out.check(u, 0, 0, which)
+        elif which == "binarize_probs_rand":
+            h.call("hipF_binarize_probs_rand", None, out.ptr, a.ptr, *zp, a.dim)
+            u, znew = O.hybrid_taus(*zwin)
+            msg = out.check(O.binarize_probs(probs, u), 0, 0, which)
+        else:
+            h.call("hipF_add_gauss_noise", None, out.ptr, f32(0.5), *zp, a.dim)
+            g, znew = O.box_muller(*zwin)
+            msg = out.check((probs + f32(0.5) * g).astype(f32), 1e-4, 1e-5, which)
+        for d, z0, zn in zip(dz, zs, znew):
+            if msg is None:
+                want = z0.copy()
+                want[a.r0:a.r0 + rows, a.c0:a.c0 + cols] = zn
+                if not (d.numpy() == want).all():
+                    msg = "generator states differ (or were advanced outside the window)"
+        return tag, msg
     if op == "rbm_update":
         N, H, V = int(rs.choice([1, 7, 64, 256])), int(rs.randint(1, 500)), int(rs.randint(1, 500))
         if rs.rand() < 0.3:
