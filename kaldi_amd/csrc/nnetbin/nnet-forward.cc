@@ -79,8 +79,12 @@ int main(int argc, char *argv[]) {
     // reader reads ahead on a thread of its own; the assigner is only used there.
     ShardAssigner shard(dist.num_ranks);
     const int32 my_rank = dist.rank;
+    kaldi::int64 table_entries = 0;  // utterances of the whole table (written by the reader's thread, read after the loop)
     PrefetchingBaseFloatMatrixReader feature_reader(
-        feature_rspecifier, [&shard, my_rank](const std::string &, int32 rows) { return shard.Assign(rows) == my_rank; });
+        feature_rspecifier, [&shard, &table_entries, my_rank](const std::string &, int32 rows) {
+          ++table_entries;
+          return shard.Assign(rows) == my_rank;
+        });
     // outputs are scanned for NaN / inf on the GPU, copied and written behind this thread
     PosteriorWriter feature_writer(feature_wspecifier);
     FeatureUploader uploader(8192);
@@ -192,7 +196,10 @@ int main(int argc, char *argv[]) {
                 << feature_reader.PayloadBytesRead() << " bytes";
     if (!silent) CuDevice::Instantiate().PrintProfile();
     DistFinalize(dist, /*need_comm=*/false);
-    return ((num_done > 0) ? 0 : 1);
+    // Like the reference, a run that found nothing to do fails (nnet-forward.cc:177).  A rank of a sharded job whose
+    // table has fewer utterances than there are ranks has nothing to do although the job has: it succeeds, and leaves
+    // an empty archive behind.
+    return ((num_done > 0 || (dist.num_ranks > 1 && table_entries > 0)) ? 0 : 1);
   } catch (const std::exception &e) {
     std::cerr << e.what();
     return -1;

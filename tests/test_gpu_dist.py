@@ -118,6 +118,30 @@ def test_forward_sharded_over_two_ranks_equals_single(hip, nn, tmp_path):
             assert read[k] == sum(b for b, w in zip(payload, want) if w == k), (rspec, read, payload, list(want))
 
 
+def test_forward_rank_with_an_empty_shard_succeeds(hip, nn, tmp_path):
+    """A table with fewer utterances than ranks: the rank that gets nothing ends with status 0 and an empty
+    archive (a single process that finds nothing to do fails, like the reference, nnet-forward.cc:177 -- but this
+    rank's job has work) -- found by tools/shard_fuzz.py.  An empty table still fails on every rank."""
+    rs = np.random.RandomState(6)
+    dims = [12, 16, 5]
+    data, _ = _model_bytes(rs, dims)
+    (tmp_path / "m.nnet").write_bytes(data)
+    utts = [("u0", rs.standard_normal((9, 12)).astype(f32)), ("u1", rs.standard_normal((4, 12)).astype(f32))]
+    (tmp_path / "f.ark").write_bytes(O.write_matrix_ark(utts))
+    (tmp_path / "empty.ark").write_bytes(b"")
+    exe = os.path.join(nn.BIN_DIR, "nnet-forward")
+    got = {}
+    for rank in range(3):
+        r = subprocess.run([exe, "--num-ranks=3", "--rank=%d" % rank, "--gpu-id=0", str(tmp_path / "m.nnet"),
+                            "ark:" + str(tmp_path / "f.ark"), "ark:" + str(tmp_path / "s.JOB.ark")], stderr=subprocess.PIPE, timeout=110)
+        assert r.returncode == 0, (rank, r.stderr.decode()[-1500:])
+        got[rank] = O.read_matrix_ark((tmp_path / ("s.%d.ark" % (rank + 1))).read_bytes())
+    assert sorted(k for v in got.values() for k, _ in v) == ["u0", "u1"] and [len(v) for v in got.values()].count(0) == 1
+    r = subprocess.run([exe, "--num-ranks=3", "--rank=1", "--gpu-id=0", str(tmp_path / "m.nnet"), "ark:" + str(tmp_path / "empty.ark"),
+                        "ark:/dev/null"], stderr=subprocess.PIPE, timeout=110)
+    assert r.returncode == 1
+
+
 @pytest.mark.parametrize("mode", ["alone", "torch"])
 def test_rccl_communicator_single_rank(hip, mode):
     """The real RCCL path of the device library (unique id, ncclCommInitRank, sum / min all-reduce, barrier,
