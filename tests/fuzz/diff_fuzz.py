@@ -4,7 +4,7 @@ sources for the CPU): random small networks, feature archives and option sets; n
 nnet-train-xent-hardlab-frmshuff models / reports of the two must agree.  Runs where a GPU and the reference
 binaries are (the GPU box); a diagnostic beside the fixture tests, which pin chosen cases.
 
-    python tools/diff_fuzz.py [--cases 40] [--seed 1] [--siblings] [--exotic] [--keep DIR]
+    python tests/fuzz/diff_fuzz.py [--cases 40] [--seed 1] [--siblings] [--exotic] [--keep DIR]
 """
 import argparse
 import os
@@ -16,7 +16,7 @@ import tempfile
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from oracle import nnet1_oracle as O  # noqa: E402
 

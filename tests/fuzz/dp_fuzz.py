@@ -2,7 +2,7 @@
 """Random check of the data-parallel training paths on one GPU (loopback communicator: R stand-in ranks that all hold
 the bunch): for random networks (odd widths, 1 to 5 layers), bunch sizes, rank counts, hyper-parameters, exchanges
 and chunk counts, R ranks on a bunch must train like ONE process on R stacked copies of it (to rounding), and the
-sharded exchange must give the bits of the summed one.     python tools/dp_fuzz.py [--cases 60] [--seed 1]
+sharded exchange must give the bits of the summed one.     python tests/fuzz/dp_fuzz.py [--cases 60] [--seed 1]
 """
 import argparse
 import os
@@ -11,7 +11,7 @@ import tempfile
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from kaldi_amd import hip as h  # noqa: E402
 import kaldi_amd.nnet as nn  # noqa: E402

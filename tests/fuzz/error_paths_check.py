@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
 """The tools of this build and of the reference (oracle/_ref/bin, CPU) on inputs that must fail -- wrong feature
 width, truncated archives and models, missing files, bad options, nothing to train on: both must refuse (non-zero
-exit status) or both succeed.  A diagnostic run on the GPU box.    python tools/error_paths_check.py"""
+exit status) or both succeed.  A diagnostic run on the GPU box.    python tests/fuzz/error_paths_check.py"""
 import os, subprocess, sys, tempfile
 import numpy as np
-ROOT = "/root/repo" if os.path.exists("/root/repo/oracle") else os.getcwd()
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from oracle import nnet1_oracle as O
 f32 = np.float32

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """nnet-forward of this build and of the reference (oracle/_ref/bin, CPU) through the table forms the recipes use --
 archives and script files, text and binary, pipes on both sides: the outputs must agree (values of text forms are
-compared after parsing).  A diagnostic run on the GPU box.    python tools/io_forms_check.py"""
+compared after parsing).  A diagnostic run on the GPU box.    python tests/fuzz/io_forms_check.py"""
 import os
 import subprocess
 import sys
@@ -9,7 +9,7 @@ import tempfile
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from oracle import nnet1_oracle as O  # noqa: E402
 

@@ -4,7 +4,7 @@ first column, rows, columns) of a buffer with its own row pitch, so pointers are
 lengths are odd, and there is memory all around the result.  Each call is compared with numpy on the window AND
 the rest of the buffer must come back untouched (a write outside the window is an error even where the values are
 right).  Shapes include one row, one column, cache-sized matrices (the flat streaming kernels) and widths around
-the kernels' internal limits.     python tools/op_fuzz.py [--cases 300] [--seed 1]
+the kernels' internal limits.     python tests/fuzz/op_fuzz.py [--cases 300] [--seed 1]
 """
 import argparse
 import ctypes
@@ -13,7 +13,7 @@ import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from kaldi_amd import hip as h  # noqa: E402
 from oracle import nnet1_oracle as O  # noqa: E402

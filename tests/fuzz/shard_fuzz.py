@@ -2,7 +2,7 @@
 """Random check of the utterance-sharded nnet-forward on one GPU: N rank processes (2 to 8) over random tables
 (1 to 40 utterances of 1 to 900 frames) read as an archive, through a script file or from a pipe; the ranks'
 archives together must be the single-process archive bit for bit, every utterance on the rank the documented
-rule gives it, and no rank may read another rank's payload.     python tools/shard_fuzz.py [--cases 12] [--seed 1]
+rule gives it, and no rank may read another rank's payload.     python tests/fuzz/shard_fuzz.py [--cases 12] [--seed 1]
 """
 import argparse
 import os
@@ -13,7 +13,7 @@ import tempfile
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import kaldi_amd.nnet as nn  # noqa: E402
 from oracle import nnet1_oracle as O  # noqa: E402

@@ -121,7 +121,7 @@ def test_forward_sharded_over_two_ranks_equals_single(hip, nn, tmp_path):
 def test_forward_rank_with_an_empty_shard_succeeds(hip, nn, tmp_path):
     """A table with fewer utterances than ranks: the rank that gets nothing ends with status 0 and an empty
     archive (a single process that finds nothing to do fails, like the reference, nnet-forward.cc:177 -- but this
-    rank's job has work) -- found by tools/shard_fuzz.py.  An empty table still fails on every rank."""
+    rank's job has work) -- found by tests/fuzz/shard_fuzz.py.  An empty table still fails on every rank."""
     rs = np.random.RandomState(6)
     dims = [12, 16, 5]
     data, _ = _model_bytes(rs, dims)

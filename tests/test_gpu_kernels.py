@@ -355,7 +355,7 @@ def test_cache_sized_streaming_kernels(hip):
 def test_row_kernels_write_their_window_only(hip, rows, cols):
     """softmax, xent_eval and the fused output layer on a WINDOW of a larger buffer whose row length is not a multiple
     of 4: the columns behind the window's last one belong to somebody else and must come back untouched (the
-    16-byte row stores once ran to the end of the last group of 4) -- found by tools/op_fuzz.py."""
+    16-byte row stores once ran to the end of the last group of 4) -- found by tests/fuzz/op_fuzz.py."""
     import ctypes
     h = hip
     rs = np.random.RandomState(31)

@@ -390,7 +390,7 @@ def test_train_tool_matches_reference(hip, nn, tmp_path, name, opts):
 def test_train_tool_shuffles_a_last_cache_shorter_than_a_bunch(hip, nn, tmp_path):
     """A table that ends with fewer frames than one bunch: the reference shuffles whatever the cache holds before it
     looks for bunches (nnetbin/nnet-train-xent-hardlab-frmshuff.cc:157-165), so its line says [RND] although no frame
-    is trained -- found by running the tools beside the reference's on random tables (tools/diff_fuzz.py)."""
+    is trained -- found by running the tools beside the reference's on random tables (tests/fuzz/diff_fuzz.py)."""
     rs = np.random.RandomState(3)
     W = (0.1 * rs.standard_normal((5, 12))).astype(f32)
     (tmp_path / "m.nnet").write_bytes(O.write_nnet([O.BiasedLinearity(W, np.zeros(5, f32)), O.Softmax(5)], True))
