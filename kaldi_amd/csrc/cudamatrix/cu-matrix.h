@@ -165,16 +165,26 @@ class CuMatrix {
     if (dst->NumRows() != num_rows_ || dst->NumCols() != num_cols_) dst->Resize(num_rows_, num_cols_, kUndefined);
     Copy2D(dst->Data(), dst->Stride(), data_, stride_, num_cols_, num_rows_, 1);
   }
-  /// this <- src[ro:ro+r, co:co+c]; this must already be r x c
+  /// this <- src for two matrices of one shape, written where this already lives: a window onto memory owned
+  /// elsewhere stays a window (CopyFromMat sizes its target, and sizing lets go of a window).  Not in the reference.
+  void AssignInPlace(const CuMatrix<Real> &src) {
+    KALDI_ASSERT(src.NumRows() == num_rows_ && src.NumCols() == num_cols_);
+    if (num_rows_ == 0 || &src == this) return;
+    Copy2D(data_, stride_, src.data_, src.stride_, num_cols_, num_rows_, 2);
+  }
+  /// this <- src[ro:ro+r, co:co+c]; this becomes r x c first (cudamatrix/cu-matrix-inl.h:168-188)
   ThisType &CopyFromMat(const CuMatrix<Real> &src, MatrixIndexT ro, MatrixIndexT r, MatrixIndexT co, MatrixIndexT c) {
-    KALDI_ASSERT(ro >= 0 && co >= 0 && ro + r <= src.NumRows() && co + c <= src.NumCols());
-    KALDI_ASSERT(r == num_rows_ && c == num_cols_);
+    KALDI_ASSERT(ro >= 0 && co >= 0 && r >= 0 && c >= 0 && ro + r <= src.NumRows() && co + c <= src.NumCols());
+    KALDI_ASSERT(&src != this);
+    Resize(r, c);
     Copy2D(data_, stride_, src.data_ + static_cast<size_t>(ro) * src.stride_ + co, src.stride_, c, r, 2);
     return *this;
   }
-  /// dst[ro:ro+rows, co:co+cols] <- this
+  /// dst[ro:ro+rows, co:co+cols] <- this.  A destination too small for the window is resized to end exactly at
+  /// the window's last row and column, which zeroes what it held (cudamatrix/cu-matrix-inl.h:242-246).
   void CopyToMat(CuMatrix<Real> *dst, MatrixIndexT ro, MatrixIndexT co) const {
-    KALDI_ASSERT(ro >= 0 && co >= 0 && ro + num_rows_ <= dst->NumRows() && co + num_cols_ <= dst->NumCols());
+    KALDI_ASSERT(ro >= 0 && co >= 0 && dst != this);
+    if (dst->NumRows() < ro + num_rows_ || dst->NumCols() < co + num_cols_) dst->Resize(ro + num_rows_, co + num_cols_);
     Copy2D(dst->data_ + static_cast<size_t>(ro) * dst->stride_ + co, dst->stride_, data_, stride_, num_cols_, num_rows_, 2);
   }
   void CopyRowsFromMat(int32 r, const CuMatrix<Real> &src, int32 src_ro, int32 dst_ro) {
@@ -340,7 +350,9 @@ void CuMatrix<Real>::AddVecToRows(Real alpha, const CuVector<Real> &row, Real be
 template <typename Real>
 void CuMatrix<Real>::AddVecToPartialRows(Real alpha, MatrixIndexT offset, const CuVector<Real> &row, Real beta) {
   CuProfileScope p(__func__);
-  KALDI_ASSERT(offset >= 0 && offset + static_cast<MatrixIndexT>(row.Dim()) <= num_cols_);
+  // the reference refuses a vector that reaches the last column too (">=", cudamatrix/cu-matrix-inl.h:793-795)
+  if (offset < 0 || static_cast<MatrixIndexT>(row.Dim()) + offset >= num_cols_)
+    KALDI_ERR << "Incorrect dimensions: Cols:" << num_cols_ << " VectorDim:" << row.Dim() << " offset:" << offset;
   CU_SAFE_CALL(hipF_add_vec_to_partial_rows(S(), alpha, offset, row.Data(), row.Dim(), beta, data_, Dim()));
 }
 }  // namespace kaldi

@@ -14,7 +14,7 @@ namespace kaldi {
 /// straight into the caller's output slot -- where CopyFromMat would let go of the window and allocate.
 inline void CopyInPlace(const CuMatrix<BaseFloat> &src, CuMatrix<BaseFloat> *dst) {
   KALDI_ASSERT(dst->NumRows() == src.NumRows() && dst->NumCols() == src.NumCols());
-  dst->CopyFromMat(src, 0, src.NumRows(), 0, src.NumCols());
+  dst->AssignInPlace(src);
 }
 
 /// y = s*x

@@ -339,7 +339,7 @@ class BiasedLinearity : public UpdatableComponent {
       return;
     }
     KALDI_ASSERT(w.NumRows() == linearity_.NumRows() && w.NumCols() == linearity_.NumCols());
-    linearity_.CopyFromMat(w, 0, w.NumRows(), 0, w.NumCols());
+    linearity_.AssignInPlace(w);
   }
   void AssignWeights(const Matrix<BaseFloat> &w) {
     if (!linearity_.IsView()) {

@@ -147,7 +147,7 @@ int main(int argc, char *argv[]) {
       if (batch_rows > 0) {
         batch_view.AttachRows(batch_in, 0, batch_rows);
         if (nnet.LayerCount() > 0) nnet.Feedforward(batch_view, nnet_out);
-        else nnet_out->CopyFromMat(batch_view, 0, batch_rows, 0, batch_view.NumCols());
+        else nnet_out->AssignInPlace(batch_view);
         finish_output(nnet_out);
       }
       feature_writer.SubmitBatch();
@@ -162,7 +162,7 @@ int main(int argc, char *argv[]) {
       if (!batching) {
         CuMatrix<BaseFloat> *nnet_out = feature_writer.Begin(mat.NumRows(), nnet.LayerCount() > 0 ? nnet.OutputDim() : feats_transf.NumCols());
         if (nnet.LayerCount() > 0) nnet.Feedforward(feats_transf, nnet_out);
-        else if (nnet_out->NumRows() > 0) nnet_out->CopyFromMat(feats_transf, 0, feats_transf.NumRows(), 0, feats_transf.NumCols());
+        else if (nnet_out->NumRows() > 0) nnet_out->AssignInPlace(feats_transf);
         finish_output(nnet_out);
         feature_writer.Submit(feature_reader.Key(), feats);
       } else {

@@ -1,0 +1,41 @@
+"""The CuMatrix / CuVector / cu:: classes against the reference's own (CPU branch): one random walk over the public
+methods, built against each code base (tests/fuzz/cumatrix_walk.cc), must leave the same matrices behind."""
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests", "fuzz"))
+
+pytestmark = pytest.mark.gpu
+
+
+def test_class_api_walk_agrees_with_the_reference_classes(tmp_path):
+    import cumatrix_walk as walk
+
+    if not os.path.exists(walk.REF):
+        pytest.skip("oracle/_ref/bin/cumatrix_walk not built (needs the reference sources at build time)")
+    assert os.path.exists(walk.OURS), "kaldi_amd/bin/cumatrix_walk missing: make -C kaldi_amd/csrc host"
+    counts, bad = {}, []
+    for seed in (101, 102):
+        fr, fo = str(tmp_path / "ref.bin"), str(tmp_path / "ours.bin")
+        walk.run(walk.REF, seed, 800, fr)
+        walk.run(walk.OURS, seed, 800, fo)
+        ref, ours = walk.read_dump(fr), walk.read_dump(fo)
+        walk.compare(seed, ref, ours, counts, bad)
+    assert not bad, "\n".join(bad[:20])
+    assert len(counts) == len(walk.OP_NAMES)  # every method group was reached
+
+
+def test_partial_row_vector_reaching_the_last_column_is_refused_as_in_the_reference():
+    import subprocess
+
+    import cumatrix_walk as walk
+
+    if not os.path.exists(walk.REF):
+        pytest.skip("oracle/_ref/bin/cumatrix_walk not built")
+    for binary in (walk.REF, walk.OURS):
+        p = subprocess.run([binary, "refused"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+        assert p.returncode != 0, binary
+        assert b"Incorrect dimensions: Cols:8 VectorDim:3 offset:5" in p.stderr, (binary, p.stderr[-500:])
