@@ -318,7 +318,11 @@ class BiasedLinearity : public UpdatableComponent {
   /// Momentum state (zero after construction; never written to disk).  With momentum 0 the
   /// correction equals the current gradient and is only stored when asked for with
   /// SetKeepGradient(true): nothing on the training path reads it and skipping the store saves
-  /// one full pass over the weight matrix per step.
+  /// one full pass over the weight matrix per step.  One consequence differs from the reference: a momentum
+  /// switched on in the middle of training (after updates with momentum 0) starts here from a zero
+  /// correction, there from the gradient of the update before (nnet/nnet-biasedlinearity.h:76-80 keeps it
+  /// always).  The trainers set the momentum once, before the first update; a caller that changes it later
+  /// and wants the reference's first step calls SetKeepGradient(true) beforehand.
   const CuMatrix<BaseFloat> &GetLinearityCorr() { return linearity_corr_; }
   const CuVector<BaseFloat> &GetBiasCorr() { return bias_corr_; }
   void SetKeepGradient(bool keep) { keep_gradient_ = keep; }

@@ -73,11 +73,13 @@ void Nnet::Propagate(const CuMatrix<BaseFloat> &in, CuMatrix<BaseFloat> *out) {
   KALDI_ASSERT(static_cast<int32>(propagate_buf_.size()) >= L + 1);
   if (borrow_input_) propagate_buf_[0].AttachRows(in, 0, in.NumRows());
   else propagate_buf_[0].CopyFromMat(in);
+  propagate_skipped_.assign(L + 1, 0);
   for (int32 i = 0; i < L; ++i) {
     const int act = fusion_ ? ActivationAfter(nnet_, i) : -1;
     WaitForLayerWeights(i);
     if (act >= 0) {
       static_cast<BiasedLinearity *>(nnet_[i])->PropagateFused(propagate_buf_[i], act, &propagate_buf_[i + 2]);
+      propagate_skipped_[i + 1] = 1;
       ++i;  // the activation has been applied
     } else {
       nnet_[i]->Propagate(propagate_buf_[i], &propagate_buf_[i + 1]);
@@ -89,8 +91,28 @@ void Nnet::Propagate(const CuMatrix<BaseFloat> &in, CuMatrix<BaseFloat> *out) {
     // Nothing reads the softmax output from the buffers during backprop (its Backpropagate only
     // forwards the error), so the result is handed over by exchanging the two allocations.
     out->Swap(&last);
+    propagate_skipped_[L] = 1;
   } else {
     out->CopyFromMat(last);
+  }
+}
+
+void Nnet::BuffersWanted(bool forward) {
+  fusion_ = false;
+  const int32 L = LayerCount();
+  if (forward) {
+    if (static_cast<int32>(propagate_skipped_.size()) != L + 1) return;  // no forward pass yet
+    FinishExchange();
+    for (int32 i = 0; i < L; ++i) {
+      if (!propagate_skipped_[i + 1]) continue;
+      nnet_[i]->Propagate(propagate_buf_[i], &propagate_buf_[i + 1]);
+      propagate_skipped_[i + 1] = 0;
+    }
+  } else {
+    for (size_t k = 0; k < backpropagate_skipped_.size() && k < backpropagate_buf_.size(); ++k) {
+      if (backpropagate_skipped_[k]) backpropagate_buf_[k].Resize(0, 0);  // (nothing stale from an earlier pass)
+      backpropagate_skipped_[k] = 0;
+    }
   }
 }
 
@@ -109,11 +131,14 @@ void Nnet::PropagateXent(const CuMatrix<BaseFloat> &in, const CuStlVector<int32>
   KALDI_ASSERT(static_cast<int32>(propagate_buf_.size()) >= L + 1);
   if (borrow_input_) propagate_buf_[0].AttachRows(in, 0, in.NumRows());
   else propagate_buf_[0].CopyFromMat(in);
+  propagate_skipped_.assign(L + 1, 0);
+  propagate_skipped_[L - 1] = 1;
   for (int32 i = 0; i < L - 2; ++i) {
     const int act = ActivationAfter(nnet_, i);
     WaitForLayerWeights(i);
     if (act >= 0) {
       static_cast<BiasedLinearity *>(nnet_[i])->PropagateFused(propagate_buf_[i], act, &propagate_buf_[i + 2]);
+      propagate_skipped_[i + 1] = 1;
       ++i;
     } else {
       nnet_[i]->Propagate(propagate_buf_[i], &propagate_buf_[i + 1]);
@@ -129,8 +154,14 @@ void Nnet::PropagateXent(const CuMatrix<BaseFloat> &in, const CuStlVector<int32>
   static_cast<BiasedLinearity *>(nnet_[L - 2])
       ->PropagateFusedXent(propagate_buf_[L - 2], target, keep_output, &last, diff, log_post, max_id, counters, loss);
   if (keep_output) {
-    if (out->NumRows() == last.NumRows() && out->NumCols() == last.NumCols()) out->Swap(&last);
-    else out->CopyFromMat(last);
+    if (out->NumRows() == last.NumRows() && out->NumCols() == last.NumCols()) {
+      out->Swap(&last);
+      propagate_skipped_[L] = 1;
+    } else {
+      out->CopyFromMat(last);
+    }
+  } else {
+    propagate_skipped_[L] = 1;
   }
 }
 
@@ -444,12 +475,14 @@ void Nnet::Backpropagate(const CuMatrix<BaseFloat> &in_err, CuMatrix<BaseFloat> 
 
   const CuMatrix<BaseFloat> *err = &in_err;  // error w.r.t. the output of layer i
   int32 i = L - 1;
+  backpropagate_skipped_.assign(L > 1 ? L - 1 : 0, 0);
   while (i >= 0) {
     Component *comp = nnet_[i];
     // where the error w.r.t. this layer's input goes (NULL: nobody wants it)
     CuMatrix<BaseFloat> *below = (i > 0) ? &backpropagate_buf_[i - 1] : out_err;
 
     if (fusion_ && comp->GetType() == Component::kSoftmax && i > 0 && comp->InputDim() == comp->OutputDim()) {
+      backpropagate_skipped_[i - 1] = 1;
       --i;  // identity on the error
       continue;
     }
@@ -461,6 +494,7 @@ void Nnet::Backpropagate(const CuMatrix<BaseFloat> &in_err, CuMatrix<BaseFloat> 
       err_ready(i, propagate_buf_[i], *err);
       if (below2 != NULL) bl->BackpropagateFused(*err, propagate_buf_[i], below2);
       update_or_defer(i, propagate_buf_[i], *err);
+      backpropagate_skipped_[i - 1] = 1;
       err = below2;
       i -= 2;
       continue;
@@ -688,8 +722,11 @@ void Nnet::Read(std::istream &in, bool binary) {
     }
     nnet_.push_back(comp);
   }
+  // A stream without a component ends the reference too: it sizes its backward buffers to LayerCount() - 1
+  // (nnet/nnet-nnet.cc:159), which throws std::length_error for -1.
+  if (LayerCount() == 0) KALDI_ERR << "No component in the model stream";
   propagate_buf_.resize(LayerCount() + 1);
-  backpropagate_buf_.resize(LayerCount() > 0 ? LayerCount() - 1 : 0);
+  backpropagate_buf_.resize(LayerCount() - 1);
   learn_rate_ = 0.0;
 }
 

@@ -4,10 +4,11 @@
 // Forward and backward passes recognise the sigmoid-DNN pattern of the hot path and run it fused
 // (SetFusion(false) restores one kernel per component):
 //   <biasedlinearity> + <sigmoid>|<softmax>  -> one GEMM whose epilogue adds the bias and applies
-//       the activation; the pre-activation buffer PropagateBuffer()[i+1] stays empty;
+//       the activation; the pre-activation buffer [i+1] of the forward pass is not written;
 //   backward through <biasedlinearity> preceded by <sigmoid> -> one GEMM whose epilogue multiplies
-//       by y(1-y); BackpropagateBuffer()[i-1] stays empty;
+//       by y(1-y); the buffer [i-1] of the backward pass is not written;
 //   <softmax> backward (a copy in the reference) -> no work, the error is used in place.
+// A caller that looks at the buffers gets the reference's: see PropagateBuffer() below.
 // The order of operations that matters for the result is the reference's (nnet-nnet.cc:50-118):
 // per layer, top down, first back-propagate through the OLD weights, then update them.
 #ifndef KALDI_AMD_NNET_NNET_NNET_H_
@@ -55,8 +56,22 @@ class Nnet {
   }
   int IndexOfLayer(const Component &comp) const;
 
-  const std::vector<CuMatrix<BaseFloat> > &PropagateBuffer() const { return propagate_buf_; }
-  const std::vector<CuMatrix<BaseFloat> > &BackpropagateBuffer() const { return backpropagate_buf_; }
+  /// Every layer's input/output of the last forward pass ([0] the input, [i+1] the output of layer i) and the
+  /// errors of the last backward pass ([i-1] w.r.t. the input of layer i), nnet/nnet-nnet.h:61-69.  The fused
+  /// passes do not write all of them, so the first call of either accessor turns fusion off: every later pass
+  /// writes every buffer, one kernel per component as the reference does (SetFusion(true) turns it back on).
+  /// For the pass that has already run, PropagateBuffer() fills in what was left out by running those components
+  /// again on their stored inputs (what the pass would have written, unless parameters changed since);
+  /// BackpropagateBuffer() cannot -- the weights that pass went through are gone -- and leaves those entries
+  /// empty until the next backward pass.
+  const std::vector<CuMatrix<BaseFloat> > &PropagateBuffer() const {
+    const_cast<Nnet *>(this)->BuffersWanted(true);
+    return propagate_buf_;
+  }
+  const std::vector<CuMatrix<BaseFloat> > &BackpropagateBuffer() const {
+    const_cast<Nnet *>(this)->BuffersWanted(false);
+    return backpropagate_buf_;
+  }
 
   void Read(const std::string &file);
   void Read(std::istream &in, bool binary);
@@ -114,6 +129,7 @@ class Nnet {
     bool pending;                 // weights_ready has been recorded and the main stream has not waited for it yet
     DpChunk() : begin(0), end(0), grad_ready(NULL), weights_read(NULL), weights_ready(NULL), pending(false) {}
   };
+  void BuffersWanted(bool forward);
   bool SetupArenas();
   void ReleaseArenas();
   void EnsureCorrectionArena();
@@ -122,6 +138,7 @@ class Nnet {
   NnetType nnet_;
   std::vector<CuMatrix<BaseFloat> > propagate_buf_;
   std::vector<CuMatrix<BaseFloat> > backpropagate_buf_;
+  std::vector<char> propagate_skipped_, backpropagate_skipped_;  // buffers the last (fused) pass did not write
   BaseFloat learn_rate_;
   bool fusion_, overlap_, borrow_input_;
   int32 dp_ranks_;

@@ -23,6 +23,7 @@ open(tmp + "/f.ark", "wb").write(ark)
 open(tmp + "/f_trunc.ark", "wb").write(ark[:len(ark) - 100])
 open(tmp + "/f_wrongdim.ark", "wb").write(O.write_matrix_ark([("u", rs.standard_normal((9, 25)).astype(f32))]))
 open(tmp + "/empty.ark", "wb").write(b"")
+open(tmp + "/empty.nnet", "wb").write(b"")
 alis = [(k, rs.randint(0, 11, m.shape[0]).astype(np.int32)) for k, m in utts]
 open(tmp + "/a.ark", "wb").write(O.write_int32_vector_ark(alis))
 cases = [
@@ -31,6 +32,9 @@ cases = [
     ("forward truncated model", "nnet-forward", [tmp + "/m_trunc.nnet", "ark:" + tmp + "/f.ark", "ark:/dev/null"]),
     ("forward truncated text model", "nnet-forward", [tmp + "/m_text_trunc.nnet", "ark:" + tmp + "/f.ark", "ark:/dev/null"]),
     ("forward empty archive", "nnet-forward", [tmp + "/m.nnet", "ark:" + tmp + "/empty.ark", "ark:/dev/null"]),
+    ("forward empty model file", "nnet-forward", [tmp + "/empty.nnet", "ark:" + tmp + "/f.ark", "ark:/dev/null"]),
+    ("forward empty transform file", "nnet-forward", ["--feature-transform=" + tmp + "/empty.nnet", tmp + "/m.nnet", "ark:" + tmp + "/f.ark", "ark:/dev/null"]),
+    ("copy empty model file", "nnet-copy", [tmp + "/empty.nnet", tmp + "/o.nnet"]),
     ("forward missing archive", "nnet-forward", [tmp + "/m.nnet", "ark:" + tmp + "/nope.ark", "ark:/dev/null"]),
     ("forward missing model", "nnet-forward", [tmp + "/nope.nnet", "ark:" + tmp + "/f.ark", "ark:/dev/null"]),
     ("forward bad option", "nnet-forward", ["--nonsense=1", tmp + "/m.nnet", "ark:" + tmp + "/f.ark", "ark:/dev/null"]),
@@ -38,6 +42,7 @@ cases = [
     ("train wrong feature dim", "nnet-train-xent-hardlab-frmshuff", ["--bunchsize=4", "--cachesize=8", "ark:" + tmp + "/f_wrongdim.ark", "ark:" + tmp + "/a.ark", tmp + "/m.nnet", tmp + "/o.nnet"]),
     ("train truncated archive", "nnet-train-xent-hardlab-frmshuff", ["--bunchsize=4", "--cachesize=8", "ark:" + tmp + "/f_trunc.ark", "ark:" + tmp + "/a.ark", tmp + "/m.nnet", tmp + "/o.nnet"]),
     ("train empty archive", "nnet-train-xent-hardlab-frmshuff", ["--bunchsize=4", "--cachesize=8", "ark:" + tmp + "/empty.ark", "ark:" + tmp + "/a.ark", tmp + "/m.nnet", tmp + "/o.nnet"]),
+    ("train empty model file", "nnet-train-xent-hardlab-frmshuff", ["--bunchsize=4", "--cachesize=8", "ark:" + tmp + "/f.ark", "ark:" + tmp + "/a.ark", tmp + "/empty.nnet", tmp + "/o.nnet"]),
     ("train missing alignments file", "nnet-train-xent-hardlab-frmshuff", ["--bunchsize=4", "--cachesize=8", "ark:" + tmp + "/f.ark", "ark:" + tmp + "/nope.ark", tmp + "/m.nnet", tmp + "/o.nnet"]),
     ("train cachesize < bunchsize", "nnet-train-xent-hardlab-frmshuff", ["--bunchsize=16", "--cachesize=8", "ark:" + tmp + "/f.ark", "ark:" + tmp + "/a.ark", tmp + "/m.nnet", tmp + "/o.nnet"]),
     ("train unwritable output", "nnet-train-xent-hardlab-frmshuff", ["--bunchsize=4", "--cachesize=8", "ark:" + tmp + "/f.ark", "ark:" + tmp + "/a.ark", tmp + "/m.nnet", "/nonexistent_dir/o.nnet"]),

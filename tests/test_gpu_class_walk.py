@@ -39,3 +39,30 @@ def test_partial_row_vector_reaching_the_last_column_is_refused_as_in_the_refere
         p = subprocess.run([binary, "refused"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
         assert p.returncode != 0, binary
         assert b"Incorrect dimensions: Cols:8 VectorDim:3 offset:5" in p.stderr, (binary, p.stderr[-500:])
+
+
+def test_network_api_walk_agrees_with_the_reference_classes(tmp_path):
+    """Nnet / Component / Xent / Mse / MseProgress / Cache: tests/fuzz/nnet_walk.cc on random model files."""
+    import numpy as np
+
+    import nnet_walk as walk
+
+    if not os.path.exists(walk.REF):
+        pytest.skip("oracle/_ref/bin/nnet_walk not built (needs the reference sources at build time)")
+    assert os.path.exists(walk.OURS), "kaldi_amd/bin/nnet_walk missing: make -C kaldi_amd/csrc host"
+    rs = np.random.RandomState(7)
+    counts, bad = {}, []
+    for case in range(16):
+        layers, desc = walk.random_model(rs)
+        binary = bool(rs.rand() < 0.5)
+        model = str(tmp_path / "m.nnet")
+        open(model, "wb").write(walk.O.write_nnet(layers, binary))
+        fr, fo = str(tmp_path / "ref.bin"), str(tmp_path / "ours.bin")
+        rc_r, err_r = walk.run(walk.REF, model, 500 + case, 50, fr)
+        rc_o, err_o = walk.run(walk.OURS, model, 500 + case, 50, fo)
+        assert (rc_r == 0) == (rc_o == 0), (desc, rc_r, rc_o, err_r[-300:], err_o[-300:])
+        if rc_r == 0:
+            walk.compare("case %d (%s)" % (case, desc), walk.read_dump(fr), walk.read_dump(fo), bad, counts)
+    assert not bad, "\n".join(bad[:20])
+    for what in ("train_err", "propagate_buffer", "backpropagate_buffer", "cache_bunch", "write_text", "xent_report"):
+        assert counts.get(what, 0) > 0, what
