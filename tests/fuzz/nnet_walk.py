@@ -128,7 +128,7 @@ def text_differs(a, b, rtol, atol, xent=False):
     return None
 
 
-def compare(name, ref, ours, bad, counts):
+def compare(name, ref, ours, bad, counts, update_tags=("train_err",)):
     if len(ref) != len(ours):
         bad.append("%s: %d / %d records" % (name, len(ref), len(ours)))
     # after training steps the two drift apart by rounding; the tolerance follows the number of updates so far
@@ -139,7 +139,7 @@ def compare(name, ref, ours, bad, counts):
             return
         what = ta.split("_", 1)[1] if ta.startswith("step") else ta
         counts[what] = counts.get(what, 0) + 1
-        if what == "train_err":
+        if what in update_tags:
             updates += 1
         rtol = 2e-5 * (1 + updates) ** 0.5
         atol = 2e-6 * (1 + updates) ** 0.5

@@ -66,3 +66,29 @@ def test_network_api_walk_agrees_with_the_reference_classes(tmp_path):
     assert not bad, "\n".join(bad[:20])
     for what in ("train_err", "propagate_buffer", "backpropagate_buffer", "cache_bunch", "write_text", "xent_report"):
         assert counts.get(what, 0) > 0, what
+
+
+def test_rbm_api_walk_agrees_with_the_reference_classes(tmp_path):
+    """Rbm: Propagate / Reconstruct / RbmUpdate / accessors / written forms, tests/fuzz/rbm_walk.cc on random stacks."""
+    import numpy as np
+
+    import rbm_walk as walk
+
+    W = walk.W
+    if not os.path.exists(walk.REF):
+        pytest.skip("oracle/_ref/bin/rbm_walk not built (needs the reference sources at build time)")
+    assert os.path.exists(walk.OURS), "kaldi_amd/bin/rbm_walk missing: make -C kaldi_amd/csrc host"
+    rs = np.random.RandomState(11)
+    counts, bad = {}, []
+    for case in range(10):
+        layers, desc = walk.random_stack(rs)
+        model = str(tmp_path / "m.rbm")
+        open(model, "wb").write(W.O.write_nnet(layers, bool(rs.rand() < 0.5)))
+        fr, fo = str(tmp_path / "ref.bin"), str(tmp_path / "ours.bin")
+        rc_r, err_r = W.run(walk.REF, model, 700 + case, 50, fr)
+        rc_o, err_o = W.run(walk.OURS, model, 700 + case, 50, fo)
+        assert rc_r == 0 and rc_o == 0, (desc, rc_r, rc_o, err_r[-300:], err_o[-300:])
+        W.compare("case %d (%s)" % (case, desc), W.read_dump(fr), W.read_dump(fo), bad, counts, update_tags=walk.UPDATES)
+    assert not bad, "\n".join(bad[:20])
+    for what in ("cd1_err", "reconstruct", "update_weight", "write_as_nnet", "write_as_decoder", "stack_feedforward"):
+        assert counts.get(what, 0) > 0, what
