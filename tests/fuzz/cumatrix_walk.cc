@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <iostream>
+#include <sstream>
 #include <string>
 #include <vector>
 
@@ -49,6 +50,15 @@ void DumpVec(const char *what, const CuVector<BaseFloat> &v) {
   v.CopyToVec(&h);
   fprintf(g_out, "%s 1 %d\n", what, static_cast<int>(h.Dim()));
   fwrite(h.Data(), sizeof(BaseFloat), h.Dim(), g_out);
+  fputc('\n', g_out);
+}
+// a text (what a stream operator or a text-mode Write produced) as a 1 x N record of byte values
+void DumpBytes(const char *what, const std::string &text) {
+  fprintf(g_out, "%s 1 %d\n", what, static_cast<int>(text.size()));
+  for (size_t i = 0; i < text.size(); ++i) {
+    const BaseFloat f = static_cast<unsigned char>(text[i]);
+    fwrite(&f, sizeof(f), 1, g_out);
+  }
   fputc('\n', g_out);
 }
 void FillMat(Lcg *g, CuMatrix<BaseFloat> *m, int r, int c, bool positive = false) {
@@ -96,7 +106,7 @@ int main(int argc, char *argv[]) {
       FillVec(&g, &vr, R, true);
       FillVec(&g, &vc, C, true);
       const BaseFloat alpha = 0.5f + g.unit(), beta = (g.below(3) == 0) ? 0.0f : 0.25f + g.unit();
-      const int op = g.below(40);
+      const int op = g.below(43);
       char tag[64];
       snprintf(tag, sizeof(tag), "step%d_op%d", step, op);
       if (getenv("WALK_TRACE")) fprintf(stderr, "%s R=%d C=%d K=%d\n", tag, R, C, K);
@@ -304,6 +314,78 @@ int main(int argc, char *argv[]) {
           FillMat(&g, &dst, 1 + g.below(R + 2), 1 + g.below(C + 2));
           A.CopyToMat(&dst, r0, c0);
           DumpMat(tag, dst);
+          break;
+        }
+        case 40: {  // the integer vector
+          const int n = 1 + g.below(300);
+          CuStlVector<int32> v(n);
+          std::vector<int32> h;
+          v.CopyToVec(&h);  // zero after construction
+          v.Set(7 - g.below(15));
+          std::vector<int32> h2;
+          v.CopyToVec(&h2);
+          h.insert(h.end(), h2.begin(), h2.end());
+          std::vector<int32> src(1 + g.below(300));
+          for (size_t i = 0; i < src.size(); ++i) src[i] = g.below(100000) - 50000;
+          v.CopyFromVec(src);  // resizes
+          v.CopyToVec(&h2);
+          h.insert(h.end(), h2.begin(), h2.end());
+          h.push_back(static_cast<int32>(v.Dim()));
+          std::ostringstream os;
+          os << v;
+          v.SetZero();
+          v.CopyToVec(&h2);
+          h.insert(h.end(), h2.begin(), h2.end());
+          v.Resize(5);
+          v.CopyToVec(&h2);
+          h.insert(h.end(), h2.begin(), h2.end());
+          fprintf(g_out, "%s 1 %d\n", tag, static_cast<int>(h.size()));
+          for (size_t i = 0; i < h.size(); ++i) {
+            const BaseFloat f = h[i];
+            fwrite(&f, sizeof(f), 1, g_out);
+          }
+          fputc('\n', g_out);
+          DumpBytes(tag, os.str());
+          break;
+        }
+        case 41: {  // a matrix through text and binary streams; whole numbers, so that the text is the same text
+          Matrix<BaseFloat> h(R, C);
+          for (int i = 0; i < R; ++i)
+            for (int j = 0; j < C; ++j) h(i, j) = g.below(2001) - 1000;
+          M.CopyFromMat(h);
+          std::ostringstream text, bin, shown;
+          M.Write(text, false);
+          M.Write(bin, true);
+          shown << M;
+          DumpBytes(tag, text.str());
+          DumpBytes(tag, bin.str());
+          DumpBytes(tag, shown.str());
+          std::istringstream from_text(text.str()), from_bin(bin.str());
+          CuMatrix<BaseFloat> X(3, 3), Y;
+          X.Read(from_text, false);
+          Y.Read(from_bin, true);
+          DumpMat(tag, X);
+          DumpMat(tag, Y);
+          break;
+        }
+        case 42: {  // and a vector
+          Vector<BaseFloat> h(C);
+          for (int j = 0; j < C; ++j) h(j) = g.below(2001) - 1000;
+          vc.CopyFromVec(h);
+          std::ostringstream text, bin, shown;
+          vc.Write(text, false);
+          vc.Write(bin, true);
+          shown << vc;
+          DumpBytes(tag, text.str());
+          DumpBytes(tag, bin.str());
+          DumpBytes(tag, shown.str());
+          std::istringstream from_text(text.str()), from_bin(bin.str());
+          CuVector<BaseFloat> x, y;
+          x.Resize(2);
+          x.Read(from_text, false);
+          y.Read(from_bin, true);
+          DumpVec(tag, x);
+          DumpVec(tag, y);
           break;
         }
       }
