@@ -5,6 +5,7 @@
 // Archive layout: for each entry  "<key> " + holder payload.  Script layout: "<key> <xfilename>\n".
 #ifndef KALDI_AMD_UTIL_KALDI_TABLE_H_
 #define KALDI_AMD_UTIL_KALDI_TABLE_H_
+#include <algorithm>
 #include <condition_variable>
 #include <deque>
 #include <exception>
@@ -308,6 +309,22 @@ class RandomAccessTableReader {
     } else if (type_ == kScriptRspecifier) {
       std::vector<std::pair<std::string, std::string> > script;
       if (!ReadScriptFile(rx, true, &script)) return false;
+      // A key that comes twice, or -- with the "s" option -- keys that are not in sorted order, refuse the table
+      // (util/kaldi-table-inl.h:1229-1246).
+      {
+        std::vector<std::string> keys(script.size());
+        for (size_t i = 0; i < script.size(); ++i) keys[i] = script[i].first;
+        if (!opts_.sorted) std::sort(keys.begin(), keys.end());
+        for (size_t i = 0; i + 1 < keys.size(); ++i) {
+          if (keys[i].compare(keys[i + 1]) >= 0) {
+            KALDI_WARN << "Script file " << PrintableRxfilename(rx)
+                       << (keys[i] == keys[i + 1] ? " contains duplicate key: "
+                                                  : " is not sorted (remove s, option or add ns, option): key is ")
+                       << keys[i];
+            return false;
+          }
+        }
+      }
       for (size_t i = 0; i < script.size(); ++i) script_[script[i].first] = script[i].second;
       eof_ = true;
     } else {
@@ -331,6 +348,13 @@ class RandomAccessTableReader {
 
  private:
   const T *Find(const std::string &key) {
+    // "s" and "cs" together: the caller has promised to ask in sorted order (util/kaldi-table-inl.h:1639-1650)
+    if (type_ == kArchiveRspecifier && opts_.sorted && opts_.called_sorted) {
+      if (!last_requested_key_.empty() && key.compare(last_requested_key_) < 0)
+        KALDI_ERR << "RandomAccessTableReader: you provided the \"cs\" option "
+                  << "but are not calling with keys in sorted order: " << key << " < " << last_requested_key_;
+      last_requested_key_ = key;
+    }
     if (opts_.once && !last_key_.empty() && last_key_ != key) {
       cache_.erase(last_key_);
       last_key_.clear();
@@ -374,6 +398,15 @@ class RandomAccessTableReader {
         }
         KALDI_ERR << "RandomAccessTableReader: failed to read object with key " << k << " from " << rspecifier_;
       }
+      if (opts_.sorted) {
+        // the archive was promised to be sorted (util/kaldi-table-inl.h:1820-1831, 1684-1688)
+        if (!newest_key_.empty() && k.compare(newest_key_) <= 0)
+          KALDI_ERR << "RandomAccessTableReader: you provide the sorted (s) option but keys in archive "
+                    << PrintableRxfilename(rspecifier_) << " are not in sorted order: " << newest_key_ << " is followed by " << k;
+      } else if (cache_.find(k) != cache_.end()) {
+        // (util/kaldi-table-inl.h:1992-1996)
+        KALDI_ERR << "Error in RandomAccessTableReader: duplicate key " << k << " in archive " << rspecifier_;
+      }
       cache_[k].reset(new T(h.Value()));
       newest_key_ = k;
       if (k == key) {
@@ -384,7 +417,7 @@ class RandomAccessTableReader {
     }
     return NULL;
   }
-  std::string rspecifier_, last_key_, newest_key_;
+  std::string rspecifier_, last_key_, newest_key_, last_requested_key_;
   RspecifierType type_;
   RspecifierOptions opts_;
   Input input_;

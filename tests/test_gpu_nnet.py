@@ -425,6 +425,36 @@ def test_train_tool_skips_missing_and_mis_sized_alignments(hip, nn, tmp_path):
     assert re.search(r"frames:60 ", err), err[-1500:]                       # u0 and u3, three whole bunches of 20
 
 
+def test_train_tool_refuses_alignment_tables_the_reference_refuses(hip, nn, tmp_path):
+    """The alignment table is read at random: a key that comes twice, an archive that is not sorted although the "s"
+    option says so, calls out of sorted order although "s,cs" says so, a script file with a repeated key -- the
+    reference stops at each (util/kaldi-table-inl.h:1229-1246, 1639-1650, 1820-1831, 1992-1996), and so does this tool."""
+    rs = np.random.RandomState(4)
+    W = (0.1 * rs.standard_normal((5, 12))).astype(f32)
+    (tmp_path / "m.nnet").write_bytes(O.write_nnet([O.BiasedLinearity(W, np.zeros(5, f32)), O.Softmax(5)], True))
+    utts = [("u%d" % i, rs.standard_normal((20, 12)).astype(f32)) for i in range(4)]
+    alis = [(k, rs.randint(0, 5, 20).astype(np.int32)) for k, _ in utts]
+    (tmp_path / "f.ark").write_bytes(O.write_matrix_ark(utts))
+    (tmp_path / "f_rev.ark").write_bytes(O.write_matrix_ark(utts[::-1]))
+    (tmp_path / "a.ark").write_bytes(O.write_int32_vector_ark(alis))
+    (tmp_path / "twice.ark").write_bytes(O.write_int32_vector_ark([alis[0], alis[1], alis[1], alis[2], alis[3]]))
+    (tmp_path / "shuffled.ark").write_bytes(O.write_int32_vector_ark([alis[2], alis[0], alis[3], alis[1]]))
+    (tmp_path / "twice.scp").write_text("u0 %s:3\nu0 %s:3\n" % (tmp_path / "a.ark", tmp_path / "a.ark"))
+
+    def train(feats, aspec, rc):
+        return run_tool(nn, "nnet-train-xent-hardlab-frmshuff", ["--bunchsize=20", "--cachesize=80", "--randomize=false",
+                        "ark:" + str(tmp_path / feats), aspec, str(tmp_path / "m.nnet"), str(tmp_path / "out.nnet")], expect_rc=rc)[1]
+
+    assert "duplicate key u1" in train("f.ark", "ark:" + str(tmp_path / "twice.ark"), 255)
+    assert "are not in sorted order: u2 is followed by u0" in train("f.ark", "ark,s:" + str(tmp_path / "shuffled.ark"), 255)
+    assert "not calling with keys in sorted order" in train("f_rev.ark", "ark,s,cs:" + str(tmp_path / "a.ark"), 255)
+    assert "contains duplicate key: u0" in train("f.ark", "scp:" + str(tmp_path / "twice.scp"), 255)
+    # and the same tables read without the claims train on every utterance
+    for feats, aspec in (("f.ark", "ark:" + str(tmp_path / "shuffled.ark")), ("f_rev.ark", "ark,s:" + str(tmp_path / "a.ark")),
+                         ("f_rev.ark", "ark,cs:" + str(tmp_path / "a.ark"))):
+        assert re.search(r"frames:80 ", train(feats, aspec, 0))
+
+
 def test_train_tool_refuses_a_table_with_nothing_to_train_on(hip, nn, tmp_path):
     """An empty feature table, or one whose utterances all lack alignments: the reference stops in
     Cache::Randomize's assertion (nnet-cache.cc:141) instead of reporting a nan accuracy; so does this tool
