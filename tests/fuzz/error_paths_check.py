@@ -24,6 +24,14 @@ open(tmp + "/f_trunc.ark", "wb").write(ark[:len(ark) - 100])
 open(tmp + "/f_wrongdim.ark", "wb").write(O.write_matrix_ark([("u", rs.standard_normal((9, 25)).astype(f32))]))
 open(tmp + "/empty.ark", "wb").write(b"")
 open(tmp + "/empty.nnet", "wb").write(b"")
+rbm = O.Rbm((0.1 * rs.standard_normal((16, 24))).astype(f32), np.zeros(24, f32), np.zeros(16, f32), "gauss", "gauss")
+rbm2 = O.Rbm((0.1 * rs.standard_normal((8, 16))).astype(f32), np.zeros(16, f32), np.zeros(8, f32), "bern", "gauss")
+open(tmp + "/r.rbm", "wb").write(O.write_nnet([rbm], True))
+open(tmp + "/r_two.rbm", "wb").write(O.write_nnet([rbm, rbm2], True))
+open(tmp + "/r_wide.rbm", "wb").write(O.write_nnet([O.Rbm((0.1 * rs.standard_normal((16, 25))).astype(f32), np.zeros(25, f32), np.zeros(16, f32), "gauss", "gauss")], True))
+rbm_bytes = O.write_nnet([rbm], True)
+open(tmp + "/r_trunc.rbm", "wb").write(rbm_bytes[:len(rbm_bytes) // 2])
+open(tmp + "/r_badtype.rbm", "wb").write(rbm_bytes.replace(b"gauss gauss", b"gauss berni", 1))
 alis = [(k, rs.randint(0, 11, m.shape[0]).astype(np.int32)) for k, m in utts]
 open(tmp + "/a.ark", "wb").write(O.write_int32_vector_ark(alis))
 cases = [
@@ -43,6 +51,23 @@ cases = [
     ("train truncated archive", "nnet-train-xent-hardlab-frmshuff", ["--bunchsize=4", "--cachesize=8", "ark:" + tmp + "/f_trunc.ark", "ark:" + tmp + "/a.ark", tmp + "/m.nnet", tmp + "/o.nnet"]),
     ("train empty archive", "nnet-train-xent-hardlab-frmshuff", ["--bunchsize=4", "--cachesize=8", "ark:" + tmp + "/empty.ark", "ark:" + tmp + "/a.ark", tmp + "/m.nnet", tmp + "/o.nnet"]),
     ("train empty model file", "nnet-train-xent-hardlab-frmshuff", ["--bunchsize=4", "--cachesize=8", "ark:" + tmp + "/f.ark", "ark:" + tmp + "/a.ark", tmp + "/empty.nnet", tmp + "/o.nnet"]),
+    ("rbm train plain", "rbm-train-cd1-frmshuff", ["--bunchsize=4", "--cachesize=128", tmp + "/r.rbm", "ark:" + tmp + "/f.ark", tmp + "/o.rbm"]),
+    ("rbm train: model is a network", "rbm-train-cd1-frmshuff", ["--bunchsize=4", "--cachesize=128", tmp + "/m.nnet", "ark:" + tmp + "/f.ark", tmp + "/o.rbm"]),
+    ("rbm train: two components", "rbm-train-cd1-frmshuff", ["--bunchsize=4", "--cachesize=128", tmp + "/r_two.rbm", "ark:" + tmp + "/f.ark", tmp + "/o.rbm"]),
+    ("rbm train: wrong feature width", "rbm-train-cd1-frmshuff", ["--bunchsize=4", "--cachesize=128", tmp + "/r_wide.rbm", "ark:" + tmp + "/f.ark", tmp + "/o.rbm"]),
+    ("rbm train: truncated model", "rbm-train-cd1-frmshuff", ["--bunchsize=4", "--cachesize=128", tmp + "/r_trunc.rbm", "ark:" + tmp + "/f.ark", tmp + "/o.rbm"]),
+    ("rbm train: unknown unit type", "rbm-train-cd1-frmshuff", ["--bunchsize=4", "--cachesize=128", tmp + "/r_badtype.rbm", "ark:" + tmp + "/f.ark", tmp + "/o.rbm"]),
+    ("rbm train: empty archive", "rbm-train-cd1-frmshuff", ["--bunchsize=4", "--cachesize=128", tmp + "/r.rbm", "ark:" + tmp + "/empty.ark", tmp + "/o.rbm"]),
+    ("rbm train: truncated archive", "rbm-train-cd1-frmshuff", ["--bunchsize=4", "--cachesize=128", tmp + "/r.rbm", "ark:" + tmp + "/f_trunc.ark", tmp + "/o.rbm"]),
+    ("rbm train: transform is the rbm itself", "rbm-train-cd1-frmshuff", ["--bunchsize=4", "--cachesize=128", "--feature-transform=" + tmp + "/r.rbm", tmp + "/r_two.rbm", "ark:" + tmp + "/f.ark", tmp + "/o.rbm"]),
+    ("rbm train: too few args", "rbm-train-cd1-frmshuff", [tmp + "/r.rbm", "ark:" + tmp + "/f.ark"]),
+    ("rbm convert plain", "rbm-convert-to-nnet", [tmp + "/r.rbm", tmp + "/o.nnet"]),
+    ("rbm convert: input is a network", "rbm-convert-to-nnet", [tmp + "/m.nnet", tmp + "/o.nnet"]),
+    ("rbm convert: two components", "rbm-convert-to-nnet", [tmp + "/r_two.rbm", tmp + "/o.nnet"]),
+    ("rbm convert: truncated", "rbm-convert-to-nnet", [tmp + "/r_trunc.rbm", tmp + "/o.nnet"]),
+    ("copy of an rbm", "nnet-copy", [tmp + "/r.rbm", tmp + "/o.rbm"]),
+    ("forward through an rbm", "nnet-forward", [tmp + "/r.rbm", "ark:" + tmp + "/f.ark", "ark:/dev/null"]),
+    ("train (backprop) through an rbm", "nnet-train-xent-hardlab-frmshuff", ["--bunchsize=4", "--cachesize=128", "ark:" + tmp + "/f.ark", "ark:" + tmp + "/a.ark", tmp + "/r.rbm", tmp + "/o.nnet"]),
     ("train missing alignments file", "nnet-train-xent-hardlab-frmshuff", ["--bunchsize=4", "--cachesize=8", "ark:" + tmp + "/f.ark", "ark:" + tmp + "/nope.ark", tmp + "/m.nnet", tmp + "/o.nnet"]),
     ("train cachesize < bunchsize", "nnet-train-xent-hardlab-frmshuff", ["--bunchsize=16", "--cachesize=8", "ark:" + tmp + "/f.ark", "ark:" + tmp + "/a.ark", tmp + "/m.nnet", tmp + "/o.nnet"]),
     ("train unwritable output", "nnet-train-xent-hardlab-frmshuff", ["--bunchsize=4", "--cachesize=8", "ark:" + tmp + "/f.ark", "ark:" + tmp + "/a.ark", tmp + "/m.nnet", "/nonexistent_dir/o.nnet"]),
