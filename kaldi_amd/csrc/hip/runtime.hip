@@ -428,10 +428,19 @@ KH_EXPORT int hipK_memcpy_2d(khStream_t s, void *dst, size_t dpitch, const void 
   if (width_bytes == 0 || height == 0) return KH_OK;
   KH_REQUIRE(dst && src && kind >= 0 && kind <= 2 && dpitch >= width_bytes && spitch >= width_bytes);
   hipStream_t st = kh::pick(s);
-  if (kind != 2 && width_bytes * height >= 65536)
-    return staged_copy_2d(st, (char *)dst, dpitch, (const char *)src, spitch, width_bytes, height, kind == 0);
+  if (kind != 2) {
+    // Between pageable host memory and the device the runtime copies a pitched matrix row by row: 9.3 us per row,
+    // whatever its length (a 366 x 40 utterance: 3.4 ms; measured, tools/h2d_probe.py).  Every copy of more than one
+    // row therefore goes through the pinned staging buffers (24-40 us for the same utterance); one row, or rows that
+    // lie back to back on both sides, are one plain copy.
+    const bool one_block = height == 1 || (dpitch == width_bytes && spitch == width_bytes);
+    if (!one_block || width_bytes * height >= 65536)
+      return staged_copy_2d(st, (char *)dst, dpitch, (const char *)src, spitch, width_bytes, height, kind == 0);
+    KH_HIP(hipMemcpyAsync(dst, src, width_bytes * height, to_kind(kind), st));
+    KH_HIP(hipStreamSynchronize(st));
+    return KH_OK;
+  }
   KH_HIP(hipMemcpy2DAsync(dst, dpitch, src, spitch, width_bytes, height, to_kind(kind), st));
-  if (kind != 2) KH_HIP(hipStreamSynchronize(st));
   return KH_OK;
 }
 

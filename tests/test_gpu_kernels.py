@@ -314,6 +314,25 @@ def test_gathers(hip):
     assert (got[:, good] == feats[:, cidx[good]]).all() and np.isposinf(got[:, 7]).all()
 
 
+def test_host_copies_of_narrow_matrices_do_not_go_row_by_row(hip):
+    """A pitched matrix copied from or to pageable host memory costs the runtime 9 us per ROW (3.4 ms for a 366 x 40
+    utterance); hipK_memcpy_2d sends every copy of more than one row through its pinned staging buffers instead
+    (about 20 us).  Values round-trip; the time is checked with a wide margin."""
+    import time
+    rs = np.random.RandomState(0)
+    for rows, cols in ((366, 40), (100, 13), (30, 120), (1, 40), (400, 1)):
+        a = rs.standard_normal((rows, cols)).astype(np.float32)
+        d = hip.DevMatrix(rows, cols)
+        d.set(a)
+        np.testing.assert_array_equal(d.numpy(), a)
+        times = []
+        for _ in range(15):
+            t0 = time.perf_counter()
+            d.set(a)
+            times.append(time.perf_counter() - t0)
+        assert sorted(times)[len(times) // 2] < 1e-3, (rows, cols, sorted(times))
+
+
 def test_cache_sized_streaming_kernels(hip):
     """The flat forms that element-wise passes and the frame shuffle take from 2^20 16-byte elements up (a whole
     frame cache): the shuffle bit for bit, the element-wise results against numpy,
