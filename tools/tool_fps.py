@@ -1,5 +1,8 @@
 """Throughput of the command-line tools on a synthetic archive, host I/O and PCIe uploads included
-(the `fps` the tools log themselves).  usage: python tools/tool_fps.py [swbd|rm] [frames]"""
+(the `fps` the tools log themselves).  usage: python tools/tool_fps.py [swbd|rm] [frames] [tool options...]
+TOOL_FPS_RAW_DIM=40: the archive holds 40-column features and the tools splice them to the network's input width with
+--feature-transform (an <expand> of input/40 frames of context), with utterances of TOOL_FPS_MIN_LEN..TOOL_FPS_MAX_LEN
+frames (default 300..1200) -- the shape speech recipes feed these tools."""
 import os
 import re
 import subprocess
@@ -17,6 +20,9 @@ which = sys.argv[1] if len(sys.argv) > 1 else "swbd"
 frames = int(sys.argv[2]) if len(sys.argv) > 2 else 200000
 extra = sys.argv[3:]  # further options for both tools, e.g. --profile=true
 dims = bench.WORKLOADS[which]["dims"]
+raw_dim = int(os.environ.get("TOOL_FPS_RAW_DIM", "0")) or dims[0]
+lo, hi = int(os.environ.get("TOOL_FPS_MIN_LEN", "300")), int(os.environ.get("TOOL_FPS_MAX_LEN", "1200"))
+assert dims[0] % raw_dim == 0 and (dims[0] // raw_dim) % 2 == 1 or raw_dim == dims[0], "input width must be an odd multiple of the raw width"
 tmp = tempfile.mkdtemp(prefix="tool_fps_", dir="/tmp")
 rs = np.random.RandomState(777)
 i32 = lambda v: b"\x04" + np.int32(v).tobytes()
@@ -25,9 +31,9 @@ n = 0
 with open(feats, "wb") as ff, open(ali, "wb") as fa:
     u = 0
     while n < frames:
-        t = int(rs.randint(300, 1201))
+        t = int(rs.randint(lo, hi + 1))
         key = ("utt%06d " % u).encode()
-        ff.write(key + b"\0BFM " + i32(t) + i32(dims[0]) + rs.standard_normal((t, dims[0])).astype("<f4").tobytes())
+        ff.write(key + b"\0BFM " + i32(t) + i32(raw_dim) + rs.standard_normal((t, raw_dim)).astype("<f4").tobytes())
         lab = rs.randint(0, dims[-1], t).astype("<i4")
         body = np.empty(t, dtype=[("s", "u1"), ("v", "<i4")])
         body["s"], body["v"] = 4, lab
@@ -36,6 +42,12 @@ with open(feats, "wb") as ff, open(ali, "wb") as fa:
         u += 1
 model = os.path.join(tmp, "in.nnet")
 bench.write_model(model, dims, seed=1)
+if raw_dim != dims[0]:
+    ctx = (dims[0] // raw_dim) // 2
+    transform = os.path.join(tmp, "splice.nnet")
+    off = np.arange(-ctx, ctx + 1, dtype="<f8")
+    open(transform, "wb").write(b"\0B<expand> " + i32(dims[0]) + i32(raw_dim) + b"DV " + i32(len(off)) + off.tobytes())
+    extra = ["--feature-transform=" + transform] + extra
 print("%s: %d utterances, %d frames, archive %.0f MB" % (which, u, n, os.path.getsize(feats) / 1e6), flush=True)
 
 
