@@ -4,7 +4,10 @@
 // matrix/kaldi-matrix.cc:1038-1265.
 #ifndef KALDI_AMD_MATRIX_KALDI_MATRIX_H_
 #define KALDI_AMD_MATRIX_KALDI_MATRIX_H_
+#include <string.h>
 #include <strings.h>
+
+#include <algorithm>
 
 #include <vector>
 
@@ -77,8 +80,22 @@ class Matrix {
       if (stride == cols) {
         os.write(reinterpret_cast<const char *>(data), sizeof(Real) * static_cast<size_t>(rows) * cols);
       } else {
-        for (MatrixIndexT r = 0; r < rows; ++r)
-          os.write(reinterpret_cast<const char *>(data + static_cast<size_t>(r) * stride), sizeof(Real) * cols);
+        // Rows of a pitched image, gathered into blocks of about 1 MiB: a stream passes every write of 1 KiB or more
+        // straight to the file, and one system call per row of a few KiB costs more than copying the row once more.
+        const size_t row_bytes = sizeof(Real) * static_cast<size_t>(cols);
+        const size_t rows_per = std::max<size_t>(1, (static_cast<size_t>(1) << 20) / std::max<size_t>(row_bytes, 1));
+        if (rows_per == 1) {
+          for (MatrixIndexT r = 0; r < rows; ++r)
+            os.write(reinterpret_cast<const char *>(data + static_cast<size_t>(r) * stride), row_bytes);
+        } else {
+          std::vector<char> block(std::min<size_t>(rows_per, rows) * row_bytes);
+          for (MatrixIndexT r0 = 0; r0 < rows; r0 += static_cast<MatrixIndexT>(rows_per)) {
+            const size_t n = std::min<size_t>(rows_per, rows - r0);
+            for (size_t r = 0; r < n; ++r)
+              memcpy(&block[r * row_bytes], data + (static_cast<size_t>(r0) + r) * stride, row_bytes);
+            os.write(&block[0], n * row_bytes);
+          }
+        }
       }
     } else if (cols == 0) {
       os << " [ ]\n";
