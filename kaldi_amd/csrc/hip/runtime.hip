@@ -4,6 +4,8 @@
 #include <string.h>
 
 #include <algorithm>
+#include <mutex>
+#include <unordered_map>
 
 #include "common.h"
 
@@ -107,6 +109,40 @@ struct SlowCall {
     if (ms > limit_ms()) fprintf(stderr, "[kaldi_hip] %s took %.1f ms\n", what, ms);
   }
 };
+// KALDI_HIP_MEM_REPORT=1: at process exit, one line (stderr) with the device memory the callers of hipK_malloc /
+// hipK_malloc_pitch held at most, what was still held at exit, and the number of allocations made.  A diagnostic for
+// soak runs (does the footprint grow with the number of utterances?); off by default, and then nothing is recorded.
+struct MemLedger {
+  std::mutex mu;
+  std::unordered_map<void *, size_t> live;
+  size_t now = 0, peak = 0, calls = 0;
+  bool on = getenv("KALDI_HIP_MEM_REPORT") != nullptr;
+  void add(void *p, size_t bytes) {
+    if (!on) return;
+    std::lock_guard<std::mutex> l(mu);
+    live[p] = bytes;
+    now += bytes;
+    peak = std::max(peak, now);
+    ++calls;
+  }
+  void drop(void *p) {
+    if (!on) return;
+    std::lock_guard<std::mutex> l(mu);
+    std::unordered_map<void *, size_t>::iterator it = live.find(p);
+    if (it == live.end()) return;
+    now -= it->second;
+    live.erase(it);
+  }
+  ~MemLedger() {
+    if (on)
+      fprintf(stderr, "[kaldi_hip] device memory held through hipK_malloc*: peak %.1f MiB, at exit %.1f MiB in %zu blocks, %zu allocations\n",
+              peak / 1048576.0, now / 1048576.0, live.size(), calls);
+  }
+};
+MemLedger &ledger() {
+  static MemLedger l;
+  return l;
+}
 }  // namespace
 
 
@@ -294,6 +330,7 @@ KH_EXPORT int hipK_malloc_pitch(void **ptr, int32_t *stride_elems, int32_t rows,
   if (rows == 0 || cols == 0) return KH_OK;
   SlowCall sc("hipMalloc");
   KH_HIP(hipMalloc(ptr, pitch * (size_t)rows));
+  ledger().add(*ptr, pitch * (size_t)rows);
   return KH_OK;
 }
 
@@ -304,6 +341,7 @@ KH_EXPORT int hipK_malloc(void **ptr, size_t bytes) {
   if (bytes == 0) return KH_OK;
   SlowCall sc("hipMalloc");
   KH_HIP(hipMalloc(ptr, bytes));
+  ledger().add(*ptr, bytes);
   return KH_OK;
 }
 
@@ -311,6 +349,7 @@ KH_EXPORT int hipK_free(void *ptr) {
   if (!ptr) return KH_OK;
   SlowCall sc("hipFree");
   KH_HIP(hipFree(ptr));
+  ledger().drop(ptr);
   return KH_OK;
 }
 

@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Soak run: the tools on long tables of utterances of very different lengths, with the host's peak resident memory per
-run and the GPU's memory in use sampled while they run (rocm-smi).  Neither may grow with the number of utterances.
+run and the device memory the run held at most (the device library's own ledger, KALDI_HIP_MEM_REPORT).  Neither may
+grow with the number of utterances.  (--poll samples rocm-smi as well; on boxes where it may not see the process it
+reports 0.)
 
     python tools/soak.py [--out FILE]
 """
@@ -57,7 +59,7 @@ def vram_used():
         return None
 
 
-POLL = True
+POLL = False
 
 
 def run(cmd):
@@ -75,7 +77,7 @@ def run(cmd):
     t.start()
     before = resource.getrusage(resource.RUSAGE_CHILDREN).ru_maxrss
     t0 = time.time()
-    r = subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+    r = subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, env=dict(os.environ, KALDI_HIP_MEM_REPORT="1"))
     dt = time.time() - t0
     stop.set()
     t.join()
@@ -86,10 +88,11 @@ def run(cmd):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=None)
-    ap.add_argument("--no-poll", action="store_true", help="do not sample rocm-smi while the tools run")
+    ap.add_argument("--poll", action="store_true", help="sample rocm-smi while the tools run")
+    ap.add_argument("--no-poll", action="store_true", help="(the default)")
     args = ap.parse_args()
     global POLL
-    POLL = not args.no_poll
+    POLL = args.poll
     rs = np.random.RandomState(1)
     tmp = tempfile.mkdtemp(prefix="soak_")
     write_model(tmp + "/m.nnet", [40, 256, 256, 120], rs)
@@ -103,11 +106,12 @@ def main():
                                                               "ark:%s/t%d.feats.ark" % (tmp, n), "ark:%s/t%d.ali.ark" % (tmp, n), tmp + "/m.nnet", tmp + "/o.nnet"])):
             rc, dt, rss, before, samples, err = run(cmd)
             vr = [s >> 20 for s in samples]
-            tail = [l for l in err.strip().splitlines() if "Done" in l or "FRAME_ACC" in l][-2:]
+            tail = [l for l in err.strip().splitlines() if "Done" in l or "device memory held" in l][-2:]
+            tail = [re.sub(r"^LOG \([^)]*\) ", "", l) for l in tail]
             lines.append("%-34s %5d utterances %8d frames: rc %d, %.1f s, peak host RSS of all runs so far %d MiB (before this run %d), "
-                         "GPU memory in use min/max %s/%s MiB over %d samples, first/last quarter max %s/%s | %s" %
-                         (tool, n, frames, rc, dt, rss >> 10, before >> 10, min(vr) if vr else None, max(vr) if vr else None, len(vr),
-                          max(vr[:max(1, len(vr) // 4)]) if vr else None, max(vr[-max(1, len(vr) // 4):]) if vr else None, " ".join(tail)[:160]))
+                         "%s| %s" %
+                         (tool, n, frames, rc, dt, rss >> 10, before >> 10,
+                          ("rocm-smi min/max %s/%s MiB over %d samples " % (min(vr), max(vr), len(vr))) if vr else "", " | ".join(tail)[:260]))
             print(lines[-1], flush=True)
         os.remove("%s/t%d.feats.ark" % (tmp, n))
         os.remove("%s/t%d.ali.ark" % (tmp, n))
