@@ -38,6 +38,12 @@ def write_model(path, dims, rs):
     open(path, "wb").write(out)
 
 
+def write_rbm(path, vis, hid, rs):
+    W = (0.05 * rs.standard_normal((hid, vis))).astype(f32)
+    open(path, "wb").write(b"\0B<rbm> " + w_i32(hid) + w_i32(vis) + b"gauss bern FM " + w_i32(hid) + w_i32(vis) + W.tobytes() +
+                           b"FV " + w_i32(vis) + np.zeros(vis, f32).tobytes() + b"FV " + w_i32(hid) + np.zeros(hid, f32).tobytes())
+
+
 def write_tables(stem, n, dim, classes, rs):
     with open(stem + ".feats.ark", "wb") as f, open(stem + ".ali.ark", "wb") as a:
         frames = 0
@@ -96,6 +102,7 @@ def main():
     rs = np.random.RandomState(1)
     tmp = tempfile.mkdtemp(prefix="soak_")
     write_model(tmp + "/m.nnet", [40, 256, 256, 120], rs)
+    write_rbm(tmp + "/r.rbm", 40, 256, rs)
     lines = []
     base = vram_used()
     lines.append("GPU memory in use before anything runs: %s MiB" % (None if base is None else base >> 20))
@@ -103,7 +110,9 @@ def main():
         frames = write_tables("%s/t%d" % (tmp, n), n, 40, 120, rs)
         for tool, cmd in (("nnet-forward", [BIN + "/nnet-forward", tmp + "/m.nnet", "ark:%s/t%d.feats.ark" % (tmp, n), "ark:/dev/null"]),
                           ("nnet-train-xent-hardlab-frmshuff", [BIN + "/nnet-train-xent-hardlab-frmshuff", "--learn-rate=0.001",
-                                                              "ark:%s/t%d.feats.ark" % (tmp, n), "ark:%s/t%d.ali.ark" % (tmp, n), tmp + "/m.nnet", tmp + "/o.nnet"])):
+                                                              "ark:%s/t%d.feats.ark" % (tmp, n), "ark:%s/t%d.ali.ark" % (tmp, n), tmp + "/m.nnet", tmp + "/o.nnet"]),
+                          ("rbm-train-cd1-frmshuff", [BIN + "/rbm-train-cd1-frmshuff", "--learn-rate=0.001", tmp + "/r.rbm",
+                                                      "ark:%s/t%d.feats.ark" % (tmp, n), tmp + "/o.rbm"])):
             rc, dt, rss, before, samples, err = run(cmd)
             vr = [s >> 20 for s in samples]
             tail = [l for l in err.strip().splitlines() if "Done" in l or "device memory held" in l][-2:]
