@@ -330,7 +330,8 @@ def test_host_copies_of_narrow_matrices_do_not_go_row_by_row(hip):
             t0 = time.perf_counter()
             d.set(a)
             times.append(time.perf_counter() - t0)
-        assert sorted(times)[len(times) // 2] < 1e-3, (rows, cols, sorted(times))
+        if rows >= 100:  # (row by row these took 0.9 and 3.4 ms; through the staging buffers about 0.02 ms)
+            assert sorted(times)[len(times) // 2] < 4e-4, (rows, cols, sorted(times))
 
 
 def test_cache_sized_streaming_kernels(hip):
