@@ -14,3 +14,4 @@ timeout -k 10 200 python -u tests/fuzz/error_paths_check.py > $o/error_paths.log
 timeout -k 10 200 python -u tests/fuzz/options_check.py > $o/options.log 2>&1; echo "options rc $?"; tail -1 $o/options.log
 timeout -k 10 300 python -u tests/fuzz/odd_inputs_check.py > $o/odd.log 2>&1; echo "odd_inputs rc $?"; tail -1 $o/odd.log | cut -c1-120
 timeout -k 10 300 python -u tests/fuzz/rbm_tool_stat_check.py > $o/rbm_stat.log 2>&1; echo "rbm_stat rc $?"; tail -1 $o/rbm_stat.log
+timeout -k 10 600 python -u tests/fuzz/extreme_shapes_check.py > $o/extreme.log 2>&1; echo "extreme_shapes rc $?"; tail -1 $o/extreme.log
