@@ -103,6 +103,7 @@ def main():
     tmp = tempfile.mkdtemp(prefix="soak_")
     write_model(tmp + "/m.nnet", [40, 256, 256, 120], rs)
     write_rbm(tmp + "/r.rbm", 40, 256, rs)
+    write_model(tmp + "/ae.nnet", [40, 256, 40], rs)  # (an auto-encoder shape for the MSE trainer: the targets are the features)
     lines = []
     base = vram_used()
     lines.append("GPU memory in use before anything runs: %s MiB" % (None if base is None else base >> 20))
@@ -111,6 +112,10 @@ def main():
         for tool, cmd in (("nnet-forward", [BIN + "/nnet-forward", tmp + "/m.nnet", "ark:%s/t%d.feats.ark" % (tmp, n), "ark:/dev/null"]),
                           ("nnet-train-xent-hardlab-frmshuff", [BIN + "/nnet-train-xent-hardlab-frmshuff", "--learn-rate=0.001",
                                                               "ark:%s/t%d.feats.ark" % (tmp, n), "ark:%s/t%d.ali.ark" % (tmp, n), tmp + "/m.nnet", tmp + "/o.nnet"]),
+                          ("nnet-train-xent-hardlab-perutt", [BIN + "/nnet-train-xent-hardlab-perutt", "--learn-rate=0.0001",
+                                                              "ark:%s/t%d.feats.ark" % (tmp, n), "ark:%s/t%d.ali.ark" % (tmp, n), tmp + "/m.nnet", tmp + "/o2.nnet"]),
+                          ("nnet-train-mse-tgtmat-frmshuff", [BIN + "/nnet-train-mse-tgtmat-frmshuff", "--learn-rate=0.0001",
+                                                              "ark:%s/t%d.feats.ark" % (tmp, n), "ark:%s/t%d.feats.ark" % (tmp, n), tmp + "/ae.nnet", tmp + "/o3.nnet"]),
                           ("rbm-train-cd1-frmshuff", [BIN + "/rbm-train-cd1-frmshuff", "--learn-rate=0.001", tmp + "/r.rbm",
                                                       "ark:%s/t%d.feats.ark" % (tmp, n), tmp + "/o.rbm"])):
             rc, dt, rss, before, samples, err = run(cmd)
