@@ -96,6 +96,7 @@ def compare(seed, ref, ours, counts, bad):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seeds", type=int, default=8)
+    ap.add_argument("--first-seed", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1500)
     ap.add_argument("--out", default=None)
     args = ap.parse_args()
@@ -104,7 +105,7 @@ def main():
             sys.exit("missing " + b + " (make -C oracle ref; make -C kaldi_amd/csrc host)")
     counts, bad, records = {}, [], 0
     with tempfile.TemporaryDirectory() as tmp:
-        for seed in range(1, args.seeds + 1):
+        for seed in range(args.first_seed, args.first_seed + args.seeds):
             fr, fo = os.path.join(tmp, "ref.bin"), os.path.join(tmp, "ours.bin")
             run(REF, seed, args.steps, fr)
             run(OURS, seed, args.steps, fo)
