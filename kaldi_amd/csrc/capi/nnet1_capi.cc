@@ -84,7 +84,7 @@ int nnet1_set_train_opts(void *h, float learn_rate, float momentum, float l2_pen
   CAPI_TRY
   Nnet &n = static_cast<Trainer *>(h)->nnet;
   n.SetLearnRate(learn_rate, (learn_factors && *learn_factors) ? learn_factors : NULL);
-  n.SetMomentum(momentum);
+  n.SetConstantMomentum(momentum);
   n.SetL2Penalty(l2_penalty);
   n.SetL2UpperBound(l2_upper_bound);
   n.SetL1Penalty(l1_penalty);

@@ -16,6 +16,9 @@ void nnet1_destroy(void *h);
 int nnet1_num_layers(void *h);
 int nnet1_input_dim(void *h);
 int nnet1_output_dim(void *h);
+/* the options of one run of the trainer tool, whose momentum is one value per process: with momentum 0 the
+ * layers do not keep the last gradient, so a later call that turns momentum on starts from a zero correction
+ * (Nnet::SetMomentum on the C++ side keeps it, as the reference does) */
 int nnet1_set_train_opts(void *h, float learn_rate, float momentum, float l2_penalty, float l1_penalty,
                          float l2_upper_bound, int average_grad, int fused, const char *learn_factors);
 int nnet1_set_data_parallel(void *h, int nranks);

@@ -315,14 +315,12 @@ class BiasedLinearity : public UpdatableComponent {
   void SetBiasWeight(const CuVector<BaseFloat> &bias) { bias_.CopyFromVec(bias); }
   void SetBiasWeight(const Vector<BaseFloat> &bias) { bias_.CopyFromVec(bias); }
   const CuVector<BaseFloat> &GetBiasWeight() { return bias_; }
-  /// Momentum state (zero after construction; never written to disk).  With momentum 0 the
-  /// correction equals the current gradient and is only stored when asked for with
-  /// SetKeepGradient(true): nothing on the training path reads it and skipping the store saves
-  /// one full pass over the weight matrix per step.  One consequence differs from the reference: a momentum
-  /// switched on in the middle of training (after updates with momentum 0) starts here from a zero
-  /// correction, there from the gradient of the update before (nnet/nnet-biasedlinearity.h:76-80 keeps it
-  /// always).  The trainers set the momentum once, before the first update; a caller that changes it later
-  /// and wants the reference's first step calls SetKeepGradient(true) beforehand.
+  /// Momentum state (zero after construction; never written to disk).  As in the reference
+  /// (nnet/nnet-biasedlinearity.h:76-82) every update stores it, so that a momentum switched on in the middle of
+  /// training starts from the gradient of the update before.  With momentum 0 nothing on the training path reads
+  /// it, and a caller whose momentum stays what it is for the rest of the run (the trainers: one value per
+  /// process) saves one full pass over the weight matrix per step with SetKeepGradient(false); a momentum that
+  /// such a caller turns on later all the same starts from the last stored correction (zero if there was none).
   const CuMatrix<BaseFloat> &GetLinearityCorr() { return linearity_corr_; }
   const CuVector<BaseFloat> &GetBiasCorr() { return bias_corr_; }
   void SetKeepGradient(bool keep) { keep_gradient_ = keep; }
@@ -365,7 +363,7 @@ class BiasedLinearity : public UpdatableComponent {
   CuMatrix<BaseFloat> linearity_corr_;
   CuVector<BaseFloat> bias_corr_;
   CuMatrix<BaseFloat> linearity_next_;  // second weight buffer (SetDoubleBuffer)
-  bool keep_gradient_ = false;
+  bool keep_gradient_ = true;
   bool double_buffer_ = false;
 };
 

@@ -788,6 +788,11 @@ std::string Nnet::GetLearnRateString() {
     if (nnet_[i]->IsUpdatable()) dynamic_cast<UpdatableComponent *>(nnet_[i])->call
 
 void Nnet::SetMomentum(BaseFloat mmt) { KALDI_AMD_FOR_UPDATABLE(SetMomentum(mmt)); }
+void Nnet::SetConstantMomentum(BaseFloat mmt) {
+  SetMomentum(mmt);
+  for (int32 i = 0; i < LayerCount(); ++i)
+    if (nnet_[i]->GetType() == Component::kBiasedLinearity) static_cast<BiasedLinearity *>(nnet_[i])->SetKeepGradient(false);
+}
 void Nnet::SetL2Penalty(BaseFloat l2) { KALDI_AMD_FOR_UPDATABLE(SetL2Penalty(l2)); }
 void Nnet::SetL2UpperBound(BaseFloat bound) { KALDI_AMD_FOR_UPDATABLE(SetL2UpperBound(bound)); }
 void Nnet::SetL1Penalty(BaseFloat l1) { KALDI_AMD_FOR_UPDATABLE(SetL1Penalty(l1)); }

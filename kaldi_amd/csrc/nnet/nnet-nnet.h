@@ -84,6 +84,9 @@ class Nnet {
   BaseFloat GetLearnRate() { return learn_rate_; }
   std::string GetLearnRateString();
   void SetMomentum(BaseFloat mmt);
+  /// SetMomentum for a caller that will not change the momentum again (not in the reference): with momentum 0
+  /// the affine layers then drop the store of the correction that only a later, non-zero momentum would read.
+  void SetConstantMomentum(BaseFloat mmt);
   void SetL2Penalty(BaseFloat l2);
   void SetL2UpperBound(BaseFloat bound);
   void SetL1Penalty(BaseFloat l1);

@@ -68,7 +68,7 @@ int main(int argc, char *argv[]) {
     Nnet nnet;
     nnet.Read(model_filename);
     nnet.SetLearnRate(learn_rate, learn_factors == "" ? NULL : learn_factors.c_str());
-    nnet.SetMomentum(momentum);
+    nnet.SetConstantMomentum(momentum);
     nnet.SetL2Penalty(l2_penalty);
     nnet.SetL1Penalty(l1_penalty);
     nnet.SetAverageGrad(average_grad);

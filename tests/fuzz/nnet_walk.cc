@@ -118,11 +118,10 @@ int main(int argc, char *argv[]) {
     MseProgress mse_progress(300);
     const int row_choices[] = {1, 2, 5, 32, 100, 256};
     nnet.SetLearnRate(0.001f, NULL);
-    // One momentum for the whole walk, set before the first update, as the trainers do.  (Switched on later, the
-    // reference's first momentum step would reuse the gradient of the update before it, which it keeps even with
-    // momentum 0 (nnet/nnet-biasedlinearity.h:76-80); this build keeps no gradient while momentum is 0.)
-    const float momentum = g.below(2) ? 0.0f : 0.1f * (1 + g.below(8));
-    nnet.SetMomentum(momentum);
+    // The momentum changes along the walk too (op 0), between zero and non-zero: the reference's first momentum step
+    // reuses the gradient of the update before it, which it keeps even with momentum 0
+    // (nnet/nnet-biasedlinearity.h:76-82).
+    nnet.SetMomentum(g.below(2) ? 0.0f : 0.1f * (1 + g.below(8)));
     // How this walk looks at the pass buffers: 0 never; 1 at the forward buffers only, whenever it likes; 2 at both,
     // having asked for them once before the first pass (a backward buffer is only there for a pass that ran after
     // the first look, see Nnet::BackpropagateBuffer of this build).
@@ -143,7 +142,7 @@ int main(int argc, char *argv[]) {
             for (int i = 0; i < updatable; ++i) factors += std::string(i ? sep[g.below(4)] : "") + f[g.below(4)];
           }
           nnet.SetLearnRate(lr, factors.empty() ? NULL : factors.c_str());
-          nnet.SetMomentum(momentum);
+          nnet.SetMomentum(g.below(2) ? 0.0f : 0.1f * (1 + g.below(8)));
           // (no L2 penalty here: the reference's CPU branch of that update asserts for a weight matrix that is not
           // square -- it adds the matrix to itself through the transposed-alias check, matrix/kaldi-matrix.cc:281)
           nnet.SetL2Penalty(0.0f);
