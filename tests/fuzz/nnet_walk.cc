@@ -148,13 +148,15 @@ int main(int argc, char *argv[]) {
           nnet.SetL2Penalty(0.0f);
           nnet.SetL1Penalty(g.below(3) ? 0.0f : 1e-5f * (1 + g.below(5)));
           nnet.SetAverageGrad(g.below(4) == 0);
+          // (a bound on the L2 norm of each weight row after the step, nnet/nnet-biasedlinearity.h:98-101)
+          nnet.SetL2UpperBound(g.below(3) ? 0.0f : 0.25f * (1 + g.below(8)));
           std::ostringstream os;
           os << nnet.GetLearnRateString() << " | " << nnet.GetLearnRate();
           for (int i = 0; i < L; ++i)
             if (nnet.Layer(i)->IsUpdatable()) {
               UpdatableComponent *uc = dynamic_cast<UpdatableComponent *>(nnet.Layer(i));
               os << " | " << uc->GetLearnRate() << " " << uc->GetMomentum() << " " << uc->GetL2Penalty() << " "
-                 << uc->GetL1Penalty() << " " << uc->GetAverageGrad();
+                 << uc->GetL1Penalty() << " " << uc->GetAverageGrad() << " " << uc->GetL2UpperBound();
             }
           DumpText(Tag(step, "knobs"), os.str());
           break;
