@@ -276,6 +276,13 @@ class CuMatrix {
     CuProfileScope p(__func__);
     CU_SAFE_CALL(hipF_apply_row_l2upperbound(S(), data_, bound, Dim()));
   }
+  /// The host-side matrix of the reference's class (cudamatrix/cu-matrix.h:187-193), which holds the data there only
+  /// when no GPU is in use and is empty otherwise.  The data of this class always live on the device: always empty,
+  /// and read-only, so that code which means to fill it does not compile.
+  const Matrix<Real> &Mat() const {
+    static const Matrix<Real> none;
+    return none;
+  }
 
  private:
   static khStream_t S() { return CuDevice::Instantiate().Stream(); }

@@ -121,6 +121,12 @@ class CuVector {
     KALDI_ASSERT(vec.Dim() == Dim());
     CU_SAFE_CALL(hipF_div_elements(S(), data_, vec.data_, D()));
   }
+  /// The host-side vector of the reference's class (cudamatrix/cu-vector.h:103-109): empty whenever the data live on
+  /// the device, which here is always.
+  const Vector<Real> &Vec() const {
+    static const Vector<Real> none;
+    return none;
+  }
 
  private:
   static khStream_t S() { return CuDevice::Instantiate().Stream(); }

@@ -106,7 +106,7 @@ int main(int argc, char *argv[]) {
       FillVec(&g, &vr, R, true);
       FillVec(&g, &vc, C, true);
       const BaseFloat alpha = 0.5f + g.unit(), beta = (g.below(3) == 0) ? 0.0f : 0.25f + g.unit();
-      const int op = g.below(43);
+      const int op = g.below(44);
       char tag[64];
       snprintf(tag, sizeof(tag), "step%d_op%d", step, op);
       if (getenv("WALK_TRACE")) fprintf(stderr, "%s R=%d C=%d K=%d\n", tag, R, C, K);
@@ -386,6 +386,29 @@ int main(int argc, char *argv[]) {
           y.Read(from_bin, true);
           DumpVec(tag, x);
           DumpVec(tag, y);
+          break;
+        }
+        case 43: {  // what the objects say about their memory, giving it back, and using them again
+          std::ostringstream os;
+          os << M.NumRows() << " " << M.NumCols() << " " << M.RowSizeInBytes() << " " << (M.Stride() >= M.NumCols()) << " "
+             << (M.SizeInBytes() == static_cast<size_t>(M.NumRows()) * M.StrideSizeInBytes()) << " "
+             << (M.StrideSizeInBytes() == M.Stride() * static_cast<MatrixIndexT>(sizeof(BaseFloat))) << " "
+             << (M.RowData(R - 1) - M.Data() == static_cast<ptrdiff_t>(R - 1) * M.Stride());
+          CuStlVector<int32> iv(K);
+          M.Destroy();
+          vc.Destroy();
+          iv.Destroy();
+          os << " | " << M.NumRows() << " " << M.NumCols() << " " << M.Stride() << " " << vc.Dim() << " " << iv.Dim();
+          M.Destroy();  // (twice is harmless)
+          M.Resize(K, R);
+          vc.Resize(K);
+          iv.Resize(R);
+          std::vector<int32> h;
+          iv.CopyToVec(&h);
+          os << " | " << M.NumRows() << " " << M.NumCols() << " " << vc.Dim() << " " << h.size() << " " << h[R - 1];
+          DumpBytes(tag, os.str());
+          DumpMat(tag, M);
+          DumpVec(tag, vc);
           break;
         }
       }

@@ -29,7 +29,8 @@ OP_NAMES = {0: "SetZero", 1: "Set", 2: "PartSet", 3: "Binarize", 4: "Add", 5: "A
             33: "RegularizeL1", 34: "PartAddMat", 35: "CopyFromMat(window)+CopyToMat(window)", 36: "Relu+DiffRelu",
             37: "SoftRelu+DiffSoftRelu", 38: "CuVector Power/ApplyLog/ApplyExp/InvertElements/Set/Resize/CopyFromVec",
             39: "CopyToMat(window past the end)", 40: "CuStlVector Set/CopyFromVec/CopyToVec/SetZero/Resize/<<",
-            41: "CuMatrix Write/Read/<< (text, binary)", 42: "CuVector Write/Read/<< (text, binary)"}
+            41: "CuMatrix Write/Read/<< (text, binary)", 42: "CuVector Write/Read/<< (text, binary)",
+            43: "sizes in bytes, Destroy, use after Destroy"}
 
 
 def read_dump(path):
