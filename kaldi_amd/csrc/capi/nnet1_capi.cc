@@ -123,6 +123,12 @@ int nnet1_keep_posteriors(void *h, int keep) {
   CAPI_CATCH(-1)
 }
 
+int nnet1_fusion_enabled(void *h) {
+  CAPI_TRY
+  return static_cast<Trainer *>(h)->nnet.GetFusion() ? 1 : 0;
+  CAPI_CATCH(-1)
+}
+
 int nnet1_feedforward(void *h, const float *feats_dev, int ld, int rows, int cols, float *out_dev, int ld_out) {
   CAPI_TRY
   Trainer *t = static_cast<Trainer *>(h);

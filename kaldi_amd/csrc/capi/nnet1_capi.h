@@ -29,6 +29,8 @@ int nnet1_train_bunch(void *h, const float *feats_dev, int ld, int rows, int col
 /* keep != 0 (default): the posteriors of the last bunch stay readable (nnet1_get_posteriors);
  * 0: the training step never writes them (the output layer, its softmax and the loss are fused) */
 int nnet1_keep_posteriors(void *h, int keep);
+/* 1 while the network runs its fused passes (Nnet::SetFusion; a look at Nnet::PropagateBuffer() turns them off) */
+int nnet1_fusion_enabled(void *h);
 /* Nnet::Feedforward; out_dev is rows x output_dim with leading dimension ld_out */
 int nnet1_feedforward(void *h, const float *feats_dev, int ld, int rows, int cols, float *out_dev, int ld_out);
 int nnet1_get_stats(void *h, long long *frames, long long *correct, double *loss);

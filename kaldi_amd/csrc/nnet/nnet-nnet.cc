@@ -829,16 +829,19 @@ void Nnet::SetDataParallel(int32 nranks) {
 }
 
 // ---- activations that look their buffers up in the owning network ------------------------------
+// (through BufferInFrontOfLayer, not PropagateBuffer(): a caller's look at the buffers turns the fused passes off,
+// the network's own components must not; what they read -- their own output, or for <softrelu> its input -- is
+// written by every forward pass, fused or not)
 void Sigmoid::BackpropagateFnc(const CuMatrix<BaseFloat> &in_err, CuMatrix<BaseFloat> *out_err) {
-  const CuMatrix<BaseFloat> &y = nnet_->PropagateBuffer()[nnet_->IndexOfLayer(*this) + 1];
+  const CuMatrix<BaseFloat> &y = nnet_->BufferInFrontOfLayer(nnet_->IndexOfLayer(*this) + 1);
   cu::DiffSigmoid(in_err, y, out_err);
 }
 void Relu::BackpropagateFnc(const CuMatrix<BaseFloat> &in_err, CuMatrix<BaseFloat> *out_err) {
-  const CuMatrix<BaseFloat> &y = nnet_->PropagateBuffer()[nnet_->IndexOfLayer(*this) + 1];
+  const CuMatrix<BaseFloat> &y = nnet_->BufferInFrontOfLayer(nnet_->IndexOfLayer(*this) + 1);
   cu::DiffRelu(in_err, y, out_err);
 }
 void SoftRelu::BackpropagateFnc(const CuMatrix<BaseFloat> &in_err, CuMatrix<BaseFloat> *out_err) {
-  const CuMatrix<BaseFloat> &x = nnet_->PropagateBuffer()[nnet_->IndexOfLayer(*this)];
+  const CuMatrix<BaseFloat> &x = nnet_->BufferInFrontOfLayer(nnet_->IndexOfLayer(*this));
   cu::DiffSoftRelu(in_err, x, out_err);
 }
 

@@ -72,6 +72,10 @@ class Nnet {
     const_cast<Nnet *>(this)->BuffersWanted(false);
     return backpropagate_buf_;
   }
+  /// For the network's own components: entry i of the forward buffers as the last pass left it, without the
+  /// side effects of PropagateBuffer().
+  const CuMatrix<BaseFloat> &BufferInFrontOfLayer(int32 i) const { return propagate_buf_[i]; }
+  bool GetFusion() const { return fusion_; }
 
   void Read(const std::string &file);
   void Read(std::istream &in, bool binary);

@@ -27,6 +27,7 @@ _SIGS = {
     "nnet1_train_bunch": (I, [P, P, I, I, I, P, I]),
     "nnet1_feedforward": (I, [P, P, I, I, I, P, I]),
     "nnet1_keep_posteriors": (I, [P, I]),
+    "nnet1_fusion_enabled": (I, [P]),
     "nnet1_get_stats": (I, [P, P, P, P]),
     "nnet1_reset_stats": (I, [P]),
     "nnet1_write": (I, [P, ctypes.c_char_p, I]),
@@ -85,6 +86,12 @@ class Trainer:
     def keep_posteriors(self, keep):
         """False: training steps do not write the posteriors (nothing reads them in a training loop)"""
         _check(lib.nnet1_keep_posteriors(self.h, int(keep)))
+
+    def fusion_enabled(self):
+        rc = lib.nnet1_fusion_enabled(self.h)
+        if rc < 0:
+            raise NnetError(lib.nnet1_last_error().decode())
+        return rc == 1
 
     def feedforward(self, feats, out):
         """feats, out: hip.DevMatrix"""

@@ -890,3 +890,27 @@ def test_dropout_component_mask_statistics_and_backprop_parity_unpinned(hip, nn,
         assert np.array_equal(fwd_kept, bwd_kept), fused
         assert abs(fwd_kept.mean() - (1 - ratio)) < 0.06
         assert np.array_equal(np.any(nW1 != W1, axis=1), bwd_kept)
+
+
+def test_components_reading_their_buffers_leave_the_fused_passes_on(hip, nn, tmp_path):
+    """<relu>, <softrelu> and a <sigmoid> that is not fused with the layer below look their activations up in the network's
+    forward buffers when they back-propagate (nnet/nnet-activation.h:27-174 of the reference does the same through
+    Nnet::PropagateBuffer()).  Here a CALLER's look at those buffers turns the fused passes off; the components' own
+    look must not: after training steps on such a network the fused passes are still on, and the steps give the bits
+    of a network that never had them on."""
+    g = load("activations_small.npz")
+    (tmp_path / "m.bin").write_bytes(g["model"].tobytes())
+    rs = np.random.RandomState(3)
+    x = hip.DevMatrix.from_numpy(rs.randn(16, 24).astype(f32))
+    t = hip.DevMatrix.from_numpy(rs.randint(0, 17, 16).astype(np.int32), pitched=False)
+    params = {}
+    for fused in (True, False):
+        tr = nn.Trainer(str(tmp_path / "m.bin"))
+        tr.set_train_opts(0.05, 0.5, 0.0, 0.0, 0.0, False, fused)
+        for _ in range(3):
+            tr.train_bunch(x.ptr, x.stride, 16, 24, t.ptr)
+        assert tr.fusion_enabled() == fused
+        params[fused] = [tr.layer_params(i, o, n) for i, o, n in ((0, 32, 24), (2, 32, 32), (5, 17, 32))]
+        tr.close()
+    for (wa, ba), (wb, bb) in zip(params[True], params[False]):
+        assert np.array_equal(wa, wb) and np.array_equal(ba, bb)
