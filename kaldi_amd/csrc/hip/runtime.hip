@@ -389,6 +389,7 @@ constexpr size_t kStageBytes = (size_t)16 << 20;
 struct Staging {
   char *buf[2] = {nullptr, nullptr};
   hipEvent_t done[2] = {nullptr, nullptr};
+  std::mutex mu;  // one copy at a time owns the two buffers (host threads of the tools' pipelines may call in)
 };
 Staging &staging() {
   static Staging s;
@@ -415,6 +416,7 @@ int staging_free() {
 // rows of `width` bytes, packed tightly in the staging buffers, chunk by chunk
 int staged_copy_2d(hipStream_t st, char *dst, size_t dpitch, const char *src, size_t spitch, size_t width, size_t height,
                    bool to_device) {
+  std::lock_guard<std::mutex> own(staging().mu);
   int rc = staging_init();
   if (rc != KH_OK) return rc;
   Staging &g = staging();

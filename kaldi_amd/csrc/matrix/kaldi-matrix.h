@@ -77,7 +77,9 @@ class Matrix {
       WriteToken(os, binary, sizeof(Real) == 4 ? "FM" : "DM");
       WriteBasicType(os, binary, static_cast<int32>(rows));
       WriteBasicType(os, binary, static_cast<int32>(cols));
-      if (stride == cols) {
+      if (rows == 0 || cols == 0) {
+        // (header only)
+      } else if (stride == cols) {
         os.write(reinterpret_cast<const char *>(data), sizeof(Real) * static_cast<size_t>(rows) * cols);
       } else {
         // Rows of a pitched image, gathered into blocks of about 1 MiB: a stream passes every write of 1 KiB or more
