@@ -15,10 +15,17 @@
 #include "base/kaldi-common.h"
 #include "cudamatrix/cu-matrix.h"
 #include "cudamatrix/cu-vector.h"
-#include "nnet/nnet-cache.h"
 #include "nnet/nnet-component.h"
-#include "nnet/nnet-loss.h"
 #include "nnet/nnet-nnet.h"
+// (the reference's activations need the network's definition in front of them, nnet/nnet-activation.h:163)
+#include "nnet/nnet-activation.h"
+#include "nnet/nnet-biasedlinearity.h"
+#include "nnet/nnet-loss.h"
+#include "nnet/nnet-cache.h"
+// the reference's two cache headers share one include guard (nnet/nnet-cache.h:19, nnet/nnet-cache-tgtmat.h:19): a
+// program that wants both has to drop it in between
+#undef KALDI_NNET_CACHE_H
+#include "nnet/nnet-cache-tgtmat.h"
 
 using namespace kaldi;
 
@@ -128,7 +135,7 @@ int main(int argc, char *argv[]) {
     const int looks = g.below(3);
     if (looks == 2) DumpText("buffers_before", nnet.BackpropagateBuffer().size() + 1 >= static_cast<size_t>(L) ? "enough" : "short");
     for (int step = 0; step < steps; ++step) {
-      const int op = g.below(12);
+      const int op = g.below(14);
       const int rows = row_choices[g.below(6)];
       if (getenv("WALK_TRACE")) fprintf(stderr, "step %d op %d rows %d\n", step, op, rows);
       CuMatrix<BaseFloat> in, out, err, in_err;
@@ -304,6 +311,83 @@ int main(int argc, char *argv[]) {
           FillMat(&g, &in, rows, in_dim);
           copy.Feedforward(in, &out);
           DumpMat(Tag(step, "reread_feedforward"), out);
+          break;
+        }
+        case 12: {  // an affine layer's weight accessors (nnet/nnet-biasedlinearity.h:104-148), the factor of a <scale>
+          std::vector<int> affine, scale;
+          for (int i = 0; i < L; ++i) {
+            if (nnet.Layer(i)->GetType() == Component::kBiasedLinearity) affine.push_back(i);
+            if (nnet.Layer(i)->GetType() == Component::kScale) scale.push_back(i);
+          }
+          if (!scale.empty() && (affine.empty() || g.below(3) == 0)) {
+            dynamic_cast<Scale *>(nnet.Layer(scale[g.below(scale.size())]))->SetScale(0.25f * (1 + g.below(8)));
+          } else if (!affine.empty()) {
+            BiasedLinearity *bl = dynamic_cast<BiasedLinearity *>(nnet.Layer(affine[g.below(affine.size())]));
+            const int O = bl->OutputDim(), I = bl->InputDim();
+            DumpMat(Tag(step, "get_linearity"), bl->GetLinearityWeight());
+            Vector<BaseFloat> bias;
+            bl->GetBiasWeight().CopyToVec(&bias);
+            std::ostringstream os;
+            for (int i = 0; i < bias.Dim(); ++i) os << bias(i) << " ";
+            DumpText(Tag(step, "get_bias"), os.str());
+            const int how = g.below(6);
+            const bool trans = how & 1;
+            if (how < 4) {  // new weights from the host or from the device, as they are or transposed
+              Matrix<BaseFloat> w(trans ? I : O, trans ? O : I);
+              for (int i = 0; i < w.NumRows(); ++i)
+                for (int j = 0; j < w.NumCols(); ++j) w(i, j) = 0.3f * g.sym();
+              if (how < 2) {
+                bl->SetLinearityWeight(w, trans);
+              } else {
+                CuMatrix<BaseFloat> dw;
+                dw.CopyFromMat(w);
+                bl->SetLinearityWeight(dw, trans);
+              }
+              Vector<BaseFloat> b(O);
+              for (int i = 0; i < O; ++i) b(i) = 0.3f * g.sym();
+              if (how & 2) {
+                CuVector<BaseFloat> db;
+                db.CopyFromVec(b);
+                bl->SetBiasWeight(db);
+              } else {
+                bl->SetBiasWeight(b);
+              }
+            } else if (how == 4) {
+              bl->SetToIdentity();
+            }
+            DumpMat(Tag(step, "set_linearity"), bl->GetLinearityWeight());
+          }
+          FillMat(&g, &in, rows, in_dim);
+          nnet.Feedforward(in, &out);
+          DumpMat(Tag(step, "accessor_feedforward"), out);
+          break;
+        }
+        case 13: {  // the cache of the trainer towards target matrices (nnet/nnet-cache-tgtmat.h)
+          CacheTgtMat cache;
+          const int bunch = 1 + g.below(64), cachesize = bunch * (1 + g.below(6));
+          cache.Init(cachesize, bunch);
+          const bool shuffle = g.below(2);
+          std::ostringstream log;
+          for (int u = 0; u < 6 && !cache.Full(); ++u) {
+            const int n = 1 + g.below(cachesize);
+            CuMatrix<BaseFloat> feats, targets;
+            FillMat(&g, &feats, n, 9);
+            FillMat(&g, &targets, n, 5);
+            cache.AddData(feats, targets);
+            log << "add " << n << " full " << cache.Full() << " empty " << cache.Empty() << " | ";
+          }
+          if (shuffle && !cache.Empty()) cache.Randomize();
+          log << "randomized " << cache.Randomized() << " | ";
+          int bunches = 0;
+          while (!cache.Empty() && bunches < 8) {
+            CuMatrix<BaseFloat> feats, targets;
+            cache.GetBunch(&feats, &targets);
+            DumpMat(Tag(step, "tgtcache_bunch"), feats);
+            DumpMat(Tag(step, "tgtcache_targets"), targets);
+            ++bunches;
+          }
+          log << "bunches " << bunches << " empty " << cache.Empty() << " full " << cache.Full();
+          DumpText(Tag(step, "tgtcache_log"), log.str());
           break;
         }
       }
