@@ -11,6 +11,7 @@
 #include <limits>
 #include <string>
 #include <type_traits>
+#include <algorithm>
 #include <vector>
 
 #include "base/kaldi-error.h"
@@ -101,8 +102,15 @@ void ReadIntegerVector(std::istream &is, bool binary, std::vector<T> *v) {
     int32 n = -1;
     is.read(reinterpret_cast<char *>(&n), sizeof(n));
     if (is.fail() || n < 0) KALDI_ERR << "ReadIntegerVector: read failure at file position " << is.tellg();
-    v->resize(n);
-    if (n > 0) is.read(reinterpret_cast<char *>(v->data()), sizeof(T) * n);
+    // (the count comes from the file: the vector grows as the bytes arrive, so a damaged count is a read error,
+    // not an allocation)
+    v->clear();
+    for (size_t done = 0; done < static_cast<size_t>(n) && !is.fail();) {
+      const size_t want = std::min<size_t>(static_cast<size_t>(n) - done, std::max<size_t>(done, 1 << 20));
+      v->resize(done + want);
+      is.read(reinterpret_cast<char *>(v->data() + done), sizeof(T) * want);
+      done += want;
+    }
   } else {
     std::vector<T> tmp;
     is >> std::ws;

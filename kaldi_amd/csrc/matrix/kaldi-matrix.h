@@ -136,24 +136,16 @@ class Matrix {
     ReadText(is);
   }
   void ReadBinaryPayload(std::istream &is, const std::string &tok, int32 r, int32 c) {
-    {
+    rows_ = cols_ = 0;
+    if (r < 0 || c < 0) {
+      data_.clear();
+      KALDI_ERR << "Failed to read matrix from stream: dimensions " << r << " x " << c;
+    }
+    if (!ReadBinaryFloats(is, static_cast<size_t>(r) * c, tok == "FM" ? 4 : 8, &data_))
+      KALDI_ERR << "Failed to read matrix from stream (" << r << " x " << c << "): truncated";
+    if (r != 0 && c != 0) {
       rows_ = r;
       cols_ = c;
-      const size_t n = static_cast<size_t>(r) * c;
-      data_.resize(n);
-      if ((tok == "FM") == (sizeof(Real) == 4)) {
-        if (n) is.read(reinterpret_cast<char *>(Data()), sizeof(Real) * n);
-      } else if (tok == "FM") {
-        std::vector<float> tmp(n);
-        if (n) is.read(reinterpret_cast<char *>(tmp.data()), 4 * n);
-        for (size_t i = 0; i < n; ++i) data_[i] = static_cast<Real>(tmp[i]);
-      } else {
-        std::vector<double> tmp(n);
-        if (n) is.read(reinterpret_cast<char *>(tmp.data()), 8 * n);
-        for (size_t i = 0; i < n; ++i) data_[i] = static_cast<Real>(tmp[i]);
-      }
-      if (is.fail()) KALDI_ERR << "Failed to read matrix from stream (" << r << " x " << c << "): truncated";
-      if (r == 0 || c == 0) rows_ = cols_ = 0;
     }
   }
   void ReadText(std::istream &is) {
@@ -189,7 +181,7 @@ class Matrix {
       } else if (c == '\n' || c == ';') {
         is.get();
         end_row();
-      } else if ((c >= '0' && c <= '9') || c == '-' || c == '.' || c == '+') {
+      } else if ((c >= '0' && c <= '9') || c == '-') {  // (what starts a number in the reference, kaldi-matrix.cc:1228)
         Real r;
         is >> r;
         if (is.fail()) KALDI_ERR << "Failed to read matrix from stream: stream failure/EOF while reading matrix data.";

@@ -3,6 +3,7 @@
 // (matrix/kaldi-vector.h); formats follow matrix/kaldi-vector.cc:846-983.
 #ifndef KALDI_AMD_MATRIX_KALDI_VECTOR_H_
 #define KALDI_AMD_MATRIX_KALDI_VECTOR_H_
+#include <ctype.h>
 #include <math.h>
 #include <strings.h>
 
@@ -85,19 +86,8 @@ class Vector {
       int32 n;
       ReadBasicType(is, binary, &n);
       if (n < 0) KALDI_ERR << "Failed to read vector from stream: negative size";
-      data_.resize(n);
-      if ((tok == "FV") == (sizeof(Real) == 4)) {
-        if (n) is.read(reinterpret_cast<char *>(Data()), sizeof(Real) * n);
-      } else if (tok == "FV") {
-        std::vector<float> tmp(n);
-        if (n) is.read(reinterpret_cast<char *>(tmp.data()), 4 * n);
-        for (int32 i = 0; i < n; ++i) data_[i] = static_cast<Real>(tmp[i]);
-      } else {
-        std::vector<double> tmp(n);
-        if (n) is.read(reinterpret_cast<char *>(tmp.data()), 8 * n);
-        for (int32 i = 0; i < n; ++i) data_[i] = static_cast<Real>(tmp[i]);
-      }
-      if (is.fail()) KALDI_ERR << "Failed to read vector from stream: truncated (size = " << n << ")";
+      if (!ReadBinaryFloats(is, static_cast<size_t>(n), tok == "FV" ? 4 : 8, &data_))
+        KALDI_ERR << "Failed to read vector from stream: truncated (size = " << n << ")";
       return;
     }
     std::string s;
@@ -108,10 +98,12 @@ class Vector {
     std::vector<Real> vals;
     for (;;) {
       const int c = is.peek();
-      if (c == '-' || (c >= '0' && c <= '9') || c == '.' || c == '+') {
+      if (c == '-' || (c >= '0' && c <= '9')) {  // (what starts a number in the reference, kaldi-vector.cc:905)
         Real r;
         is >> r;
         if (is.fail()) KALDI_ERR << "Failed to read vector from stream: failed to read number.";
+        if (!isspace(is.peek()) && is.peek() != ']')
+          KALDI_ERR << "Failed to read vector from stream: expected whitespace after number.";
         vals.push_back(r);
       } else if (c == ' ' || c == '\t') {
         is.get();

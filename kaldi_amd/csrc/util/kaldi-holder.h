@@ -4,6 +4,7 @@
 //   basic vector : binary "\0B" int32 n, then n basic values; text: "v0 v1 ... \n"
 #ifndef KALDI_AMD_UTIL_KALDI_HOLDER_H_
 #define KALDI_AMD_UTIL_KALDI_HOLDER_H_
+#include <algorithm>
 #include <functional>
 #include <sstream>
 #include <string>
@@ -139,8 +140,14 @@ class BasicVectorHolder {
         int32 n;
         ReadBasicType(is, true, &n);
         if (n < 0) return false;
-        t_.resize(n);
-        for (int32 i = 0; i < n; ++i) ReadBasicType(is, true, &t_[i]);
+        // (the count comes from the file: the vector grows as the elements arrive, so a damaged count is a read
+        // error, not an allocation)
+        t_.reserve(std::min<int32>(n, 1 << 20));
+        for (int32 i = 0; i < n; ++i) {
+          BasicType v;
+          ReadBasicType(is, true, &v);
+          t_.push_back(v);
+        }
       } else {
         std::string line;
         std::getline(is, line);
@@ -162,6 +169,15 @@ class BasicVectorHolder {
       KALDI_WARN << "BasicVectorHolder::Read, read error or unexpected data";
       return false;
     }
+  }
+  /// The filtered read of the sequential reader (see KaldiObjectHolder::ReadIf): a vector is read whole and then
+  /// kept or dropped by its length.
+  bool ReadIf(std::istream &is, const std::function<bool(int32)> &keep, bool *kept, size_t *payload_read) {
+    if (!Read(is)) return false;
+    *kept = keep(static_cast<int32>(t_.size()));
+    if (payload_read) *payload_read += t_.size() * sizeof(BasicType);
+    if (!*kept) t_.clear();
+    return true;
   }
   const T &Value() const { return t_; }
   void Clear() { t_.clear(); }

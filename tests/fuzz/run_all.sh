@@ -15,3 +15,5 @@ timeout -k 10 200 python -u tests/fuzz/options_check.py > $o/options.log 2>&1; e
 timeout -k 10 300 python -u tests/fuzz/odd_inputs_check.py > $o/odd.log 2>&1; echo "odd_inputs rc $?"; tail -1 $o/odd.log | cut -c1-120
 timeout -k 10 300 python -u tests/fuzz/rbm_tool_stat_check.py > $o/rbm_stat.log 2>&1; echo "rbm_stat rc $?"; tail -1 $o/rbm_stat.log
 timeout -k 10 600 python -u tests/fuzz/extreme_shapes_check.py > $o/extreme.log 2>&1; echo "extreme_shapes rc $?"; tail -1 $o/extreme.log
+timeout -k 10 300 python -u tests/fuzz/table_mutation.py --cases 1500 --seed 4 > $o/table_mutation.log 2>&1; echo "table_mutation rc $?"; head -1 $o/table_mutation.log
+timeout -k 10 300 python -u tests/fuzz/model_mutation.py --cases 600 --seed 4 > $o/model_mutation.log 2>&1; echo "model_mutation rc $?"; head -1 $o/model_mutation.log
