@@ -4,10 +4,15 @@
 
 namespace kaldi {
 
+// util/text-utils.cc:86-97 of the reference: non-empty, and no ASCII character that is not printable or is a space;
+// bytes above 127 pass (accented letters), except 255 (a form of space).
 bool IsToken(const std::string &s) {
   if (s.empty()) return false;
-  for (char c : s)
-    if (isspace(static_cast<unsigned char>(c))) return false;
+  for (char ch : s) {
+    const unsigned char c = static_cast<unsigned char>(ch);
+    if (c == 255) return false;
+    if (c < 128 && (!isprint(c) || isspace(c))) return false;
+  }
   return true;
 }
 

@@ -41,7 +41,7 @@ RspecifierType ClassifyRspecifier(const std::string &rspecifier, std::string *rx
 /// reads "key xfilename" lines; false on a malformed line
 bool ReadScriptFile(const std::string &rxfilename, bool print_warnings,
                     std::vector<std::pair<std::string, std::string> > *script_out);
-bool IsToken(const std::string &s);  // non-empty, no whitespace
+bool IsToken(const std::string &s);  // a valid table key (util/text-utils.cc:86 of the reference)
 
 // ---- sequential reader ---------------------------------------------------------------------
 template <class Holder>
@@ -333,7 +333,10 @@ class RandomAccessTableReader {
     return true;
   }
   bool IsOpen() const { return type_ != kNoRspecifier; }
-  bool HasKey(const std::string &key) { return Find(key) != NULL; }
+  bool HasKey(const std::string &key) {
+    if (!IsToken(key)) KALDI_ERR << "RandomAccessTableReader::HasKey, invalid key \"" << key << '"';
+    return Find(key) != NULL;
+  }
   const T &Value(const std::string &key) {
     const T *t = Find(key);
     if (!t) KALDI_ERR << "RandomAccessTableReader: Value() called for key " << key << " which is not present, reading " << rspecifier_;

@@ -17,3 +17,4 @@ timeout -k 10 300 python -u tests/fuzz/rbm_tool_stat_check.py > $o/rbm_stat.log 
 timeout -k 10 600 python -u tests/fuzz/extreme_shapes_check.py > $o/extreme.log 2>&1; echo "extreme_shapes rc $?"; tail -1 $o/extreme.log
 timeout -k 10 300 python -u tests/fuzz/table_mutation.py --cases 1500 --seed 4 > $o/table_mutation.log 2>&1; echo "table_mutation rc $?"; head -1 $o/table_mutation.log
 timeout -k 10 300 python -u tests/fuzz/model_mutation.py --cases 600 --seed 4 > $o/model_mutation.log 2>&1; echo "model_mutation rc $?"; head -1 $o/model_mutation.log
+timeout -k 10 600 python -u tests/fuzz/archive_mutation.py --cases 200 --seed 4 > $o/archive_mutation.log 2>&1; echo "archive_mutation rc $?"; grep "^archive_mutation" $o/archive_mutation.log
