@@ -81,6 +81,8 @@ int main(int argc, char *argv[]) {
     SequentialBaseFloatMatrixReader targets_reader(targets_rspecifier);
 
     CacheTgtMat cache;
+    // (the reference divides by it first and dies of the division, nnetbin/nnet-train-xent-hardlab-frmshuff.cc:115)
+    if (bunchsize <= 0) KALDI_ERR << "--bunchsize must be positive, got " << bunchsize;
     cachesize = (cachesize / bunchsize) * bunchsize;
     cache.Init(cachesize, bunchsize);
     Mse mse;

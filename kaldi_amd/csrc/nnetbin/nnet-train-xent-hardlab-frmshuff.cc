@@ -104,6 +104,8 @@ int main(int argc, char *argv[]) {
     RandomAccessInt32VectorReader alignments_reader(alignments_rspecifier);
 
     Cache cache;
+    // (the reference divides by it first and dies of the division, nnetbin/nnet-train-xent-hardlab-frmshuff.cc:115)
+    if (bunchsize <= 0) KALDI_ERR << "--bunchsize must be positive, got " << bunchsize;
     cachesize = (cachesize / bunchsize) * bunchsize;  // a whole number of bunches
     cache.Init(cachesize, bunchsize);
 

@@ -69,6 +69,8 @@ int main(int argc, char *argv[]) {
     PrefetchingBaseFloatMatrixReader feature_reader(feature_rspecifier);  // reads ahead on a thread of its own
 
     Cache cache;
+    // (the reference divides by it first and dies of the division, nnetbin/nnet-train-xent-hardlab-frmshuff.cc:115)
+    if (bunchsize <= 0) KALDI_ERR << "--bunchsize must be positive, got " << bunchsize;
     cachesize = (cachesize / bunchsize) * bunchsize;
     cache.Init(cachesize, bunchsize);
 

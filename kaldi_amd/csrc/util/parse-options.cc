@@ -139,9 +139,10 @@ int ParseOptions::Read(int argc, const char *const *argv) {
   if (argc > 0) SetProgramName(argv[0]);
   // config files first, so that the command line overrides them
   int i;
+  // (this pass looks at every argument, also behind the first positional one: util/parse-options.cc:277-290)
   for (i = 1; i < argc; ++i) {
     const std::string a = argv[i];
-    if (a.compare(0, 2, "--") != 0) break;
+    if (a.compare(0, 2, "--") != 0) continue;
     const std::string key = Normalize(a.substr(2, a.find('=') == std::string::npos ? std::string::npos : a.find('=') - 2));
     if (key == "config") ReadConfigFile(TrimCopy(a.substr(a.find('=') == std::string::npos ? a.size() : a.find('=') + 1)));
     if (key == "help") {
