@@ -19,3 +19,4 @@ timeout -k 10 300 python -u tests/fuzz/table_mutation.py --cases 1500 --seed 4 >
 timeout -k 10 300 python -u tests/fuzz/model_mutation.py --cases 600 --seed 4 > $o/model_mutation.log 2>&1; echo "model_mutation rc $?"; head -1 $o/model_mutation.log
 timeout -k 10 600 python -u tests/fuzz/archive_mutation.py --cases 200 --seed 4 > $o/archive_mutation.log 2>&1; echo "archive_mutation rc $?"; grep "^archive_mutation" $o/archive_mutation.log
 timeout -k 10 600 python -u tests/fuzz/options_mutation.py --cases 400 --seed 4 > $o/options_mutation.log 2>&1; echo "options_mutation rc $?"; grep "^options_mutation" $o/options_mutation.log
+timeout -k 10 600 python -u tests/fuzz/specifier_mutation.py --cases 400 --seed 4 > $o/specifier_mutation.log 2>&1; echo "specifier_mutation rc $?"; grep "^specifier_mutation" $o/specifier_mutation.log
