@@ -34,7 +34,15 @@ def main():
     have_ref = os.path.exists(os.path.join(REF, "nnet-copy"))
     with tempfile.TemporaryDirectory() as tmp:
         for case in range(args.cases):
-            layers, desc = W.random_model(rs)
+            tool = "nnet-copy"
+            if rs.rand() < 0.3:   # one <rbm> through the converter (nnetbin/rbm-convert-to-nnet.cc)
+                tool = "rbm-convert-to-nnet"
+                v, h = int(rs.choice([3, 7, 16, 33])), int(rs.choice([3, 7, 16, 33]))
+                layers = [O.Rbm((0.1 * rs.standard_normal((h, v))).astype(np.float32), (0.1 * rs.standard_normal(v)).astype(np.float32),
+                                (0.1 * rs.standard_normal(h)).astype(np.float32), "gauss" if rs.rand() < 0.5 else "bern", "bern")]
+                desc = "rbm %dx%d" % (v, h)
+            else:
+                layers, desc = W.random_model(rs)
             if not layers:
                 continue
             binary = bool(rs.rand() < 0.5)
@@ -45,8 +53,10 @@ def main():
             for which, d in (("ours", OURS), ("ref", REF)):
                 if which == "ref" and not have_ref:
                     continue
+                if os.path.exists(os.path.join(tmp, "o_" + which)):
+                    os.remove(os.path.join(tmp, "o_" + which))
                 try:
-                    r = subprocess.run([os.path.join(d, "nnet-copy"), "--binary=true", f, os.path.join(tmp, "o_" + which)],
+                    r = subprocess.run([os.path.join(d, tool), "--binary=true", f, os.path.join(tmp, "o_" + which)],
                                        capture_output=True, timeout=100)
                     res[which] = r.returncode
                 except subprocess.TimeoutExpired:
@@ -76,7 +86,7 @@ def main():
     lines = ["model_mutation: %d damaged models, %d findings" % (sum(counts.values()), len(findings))]
     lines += ["  %-20s %d" % kv for kv in sorted(counts.items())]
     if both:
-        lines.append("  accept / refuse as the reference's nnet-copy does: %d of %d" % (agree, both))
+        lines.append("  accept / refuse as the reference's tool does: %d of %d" % (agree, both))
         lines.append("  copied by both: %d, the same bytes: %d" % (copied_both, same_bytes))
         lines += notes
     lines += findings
