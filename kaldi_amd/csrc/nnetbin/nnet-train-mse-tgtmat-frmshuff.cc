@@ -104,7 +104,10 @@ int main(int argc, char *argv[]) {
           feature_reader.Next();
           if (!feature_reader.Done()) fea_key = feature_reader.Key();
         }
-        if (feature_reader.Done()) break;
+        // (targets whose features never come: the reference asks the exhausted feature reader for its key here and
+        // dies of that, nnetbin/nnet-train-mse-tgtmat-frmshuff.cc:136-142, util/kaldi-table-inl.h:423)
+        if (feature_reader.Done())
+          KALDI_ERR << "Key() called on TableReader object at the wrong time: no features for the targets of " << tgt_key;
         const Matrix<BaseFloat> &fea_mat = feature_reader.Value();
         const Matrix<BaseFloat> &tgt_mat = targets_reader.Value();
         if (tgt_mat.NumRows() != fea_mat.NumRows()) {

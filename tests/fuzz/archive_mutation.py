@@ -52,18 +52,26 @@ def main():
     with tempfile.TemporaryDirectory() as tmp:
         P = lambda n: os.path.join(tmp, n)  # noqa: E731
         open(P("m.nnet"), "wb").write(O.write_nnet(layers, True))
+        open(P("r.rbm"), "wb").write(O.write_nnet([O.Rbm((0.1 * rs.randn(H, D)).astype(f32), np.zeros(D, f32), np.zeros(H, f32), "gauss", "bern")], True))
         for case in range(args.cases):
             utts = [("utt%d" % i, rs.randn(int(rs.randint(1, 30)), D).astype(f32)) for i in range(5)]
             alis = [(k, rs.randint(0, C, m.shape[0])) for k, m in utts]
             feats = O.write_matrix_ark(utts) if rs.rand() < 0.6 else text_matrix_ark(utts)
             ali = text_ali_ark(alis) if rs.rand() < 0.6 else binary_ali_ark(alis)
-            what = int(rs.randint(0, 3))  # 0: forward on damaged features; 1: train on damaged features; 2: train on damaged alignments
-            if what < 2:
+            # 0: forward on damaged features; 1: train on damaged features; 2: train on damaged alignments; then the sibling
+            # trainers: 3 per-utterance, damaged features or alignments; 4 / 5 towards target matrices, damaged features /
+            # targets; 6 contrastive divergence on damaged features (this build alone)
+            what = int(rs.randint(0, 7))
+            tgts = O.write_matrix_ark([(k, rs.rand(m.shape[0], C).astype(f32)) for k, m in utts])
+            if what in (0, 1, 4, 6) or (what == 3 and rs.rand() < 0.5):
                 feats = mutate(rs, feats)
+            elif what == 5:
+                tgts = mutate(rs, tgts)
             else:
                 ali = mutate(rs, ali)
             open(P("f.ark"), "wb").write(feats)
             open(P("a.ark"), "wb").write(ali)
+            open(P("t.ark"), "wb").write(tgts)
             res = {}
             for which, d in (("ref", REF), ("ours", OURS)):
                 out = P("out_" + which)
@@ -71,18 +79,34 @@ def main():
                     os.remove(out)
                 if what == 0:
                     rc, err = run(d, "nnet-forward", [P("m.nnet"), "ark:" + P("f.ark"), "ark:" + out])
+                elif what == 3:
+                    rc, err = run(d, "nnet-train-xent-hardlab-perutt", ["--learn-rate=0.01", "--binary=true", "ark:" + P("f.ark"), "ark:" + P("a.ark"),
+                                                                        P("m.nnet"), out])
+                elif what in (4, 5):
+                    rc, err = run(d, "nnet-train-mse-tgtmat-frmshuff",
+                                  ["--bunchsize=8", "--cachesize=64", "--learn-rate=0.05", "--binary=true",
+                                   "ark:" + P("f.ark"), "ark:" + P("t.ark"), P("m.nnet"), out])
+                elif what == 6:
+                    rc, err = run(d, "rbm-train-cd1-frmshuff", ["--bunchsize=8", "--cachesize=64", "--learn-rate=0.01", "--binary=true",
+                                                                P("r.rbm"), "ark:" + P("f.ark"), out])
                 else:
                     rc, err = run(d, "nnet-train-xent-hardlab-frmshuff",
                                   ["--bunchsize=8", "--cachesize=64", "--learn-rate=0.05", "--randomize=false", "--binary=true",
                                    "ark:" + P("f.ark"), "ark:" + P("a.ark"), P("m.nnet"), out])
                 res[which] = (rc, err, out)
             (rc_r, err_r, out_r), (rc_o, err_o, out_o) = res["ref"], res["ours"]
-            name = "case %d (%s)" % (case, ("forward, damaged features", "train, damaged features", "train, damaged alignments")[what])
+            name = "case %d (%s)" % (case, ("forward, damaged features", "train, damaged features", "train, damaged alignments",
+                                            "per-utterance trainer", "trainer towards targets, damaged features",
+                                            "trainer towards targets, damaged targets", "rbm trainer, damaged features")[what])
             kind = "both accept" if rc_r == 0 and rc_o == 0 else "both refuse" if rc_r != 0 and rc_o != 0 else "one refuses"
             why = []
             if rc_o not in (0, 1, 255, -6):
                 why.append("this build ends with %s" % rc_o)
-            if rc_r == "timeout":
+            if what == 6:
+                # the reference's CPU build cannot run this tool on any input (its sampler's CPU branch never sizes its
+                # output, cu-rand-inl.h:162-168): only this build's own end is looked at
+                kind = "rbm trainer: " + ("trained" if rc_o == 0 else "refused")
+            elif rc_r == "timeout":
                 kind = "the reference does not end"   # (an alignment of the wrong length: it never returns)
             elif kind == "one refuses" and rc_r == 0 and "outside the network's" in err_o:
                 # the reference's CPU branch indexes the posterior row with such a label (cu-math-inl.h:373-377)
@@ -104,7 +128,7 @@ def main():
                             if ka != kb or x.shape != y.shape or not np.allclose(x, y, rtol=1e-4, atol=1e-6, equal_nan=True):
                                 why.append("output %s / %s differs" % (ka, kb))
                                 break
-            elif kind == "both accept":
+            elif kind == "both accept" and what != 6:
                 la = [l for l in O.read_nnet(open(out_r, "rb").read()) if isinstance(l, O.BiasedLinearity)]
                 lb = [l for l in O.read_nnet(open(out_o, "rb").read()) if isinstance(l, O.BiasedLinearity)]
                 if any(not np.allclose(x.W, y.W, rtol=1e-3, atol=1e-5, equal_nan=True) for x, y in zip(la, lb)):
@@ -116,7 +140,7 @@ def main():
                 differ.append("%s: %s\n    ref : %s\n    ours: %s" % (name, "; ".join(why), err_r.strip().split("\n")[-1][:200] if err_r else "",
                                                                      err_o.strip().split("\n")[-1][:200] if err_o else ""))
                 os.makedirs(os.path.join(ROOT, "gpurun_out", "archive_mutation"), exist_ok=True)
-                for n in ("f.ark", "a.ark", "m.nnet"):
+                for n in ("f.ark", "a.ark", "t.ark", "m.nnet"):
                     open(os.path.join(ROOT, "gpurun_out", "archive_mutation", "case%d_%s" % (case, n)), "wb").write(open(P(n), "rb").read())
     lines = ["archive_mutation: %d cases, %d differ" % (args.cases, len(differ))]
     lines += ["  %-28s %d" % kv for kv in sorted(counts.items())] + differ
