@@ -43,6 +43,7 @@ def main():
     ap.add_argument("--cases", type=int, default=200)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--out", default=None)
+    ap.add_argument("--only", type=int, default=-1, help="one kind of case only (0..7, see the list in the loop)")
     args = ap.parse_args()
     rs = np.random.RandomState(args.seed)
     D, H, C = 13, 24, 9
@@ -61,7 +62,10 @@ def main():
             # 0: forward on damaged features; 1: train on damaged features; 2: train on damaged alignments; then the sibling
             # trainers: 3 per-utterance, damaged features or alignments; 4 / 5 towards target matrices, damaged features /
             # targets; 6 contrastive divergence on damaged features (this build alone)
-            what = int(rs.randint(0, 7))
+            # 7: forward with damaged class frame counts (a vector file, text or binary)
+            what = int(rs.randint(0, 8))
+            if args.only >= 0:
+                what = args.only
             tgts = O.write_matrix_ark([(k, rs.rand(m.shape[0], C).astype(f32)) for k, m in utts])
             if what in (0, 1, 4, 6) or (what == 3 and rs.rand() < 0.5):
                 feats = mutate(rs, feats)
@@ -72,6 +76,13 @@ def main():
             open(P("f.ark"), "wb").write(feats)
             open(P("a.ark"), "wb").write(ali)
             open(P("t.ark"), "wb").write(tgts)
+            if what == 7:
+                cnt = rs.randint(1, 1000, C).astype(f32)
+                if rs.rand() < 0.5:
+                    counts_file = (" [ " + " ".join("%g" % v for v in cnt) + " ]\n").encode()
+                else:
+                    counts_file = b"\0BFV \x04" + np.int32(C).tobytes() + cnt.tobytes()
+                open(P("c.counts"), "wb").write(mutate(rs, counts_file))
             res = {}
             for which, d in (("ref", REF), ("ours", OURS)):
                 out = P("out_" + which)
@@ -79,6 +90,9 @@ def main():
                     os.remove(out)
                 if what == 0:
                     rc, err = run(d, "nnet-forward", [P("m.nnet"), "ark:" + P("f.ark"), "ark:" + out])
+                elif what == 7:
+                    rc, err = run(d, "nnet-forward", ["--class-frame-counts=" + P("c.counts"), "--apply-log=true", P("m.nnet"),
+                                                      "ark:" + P("f.ark"), "ark:" + out])
                 elif what == 3:
                     rc, err = run(d, "nnet-train-xent-hardlab-perutt", ["--learn-rate=0.01", "--binary=true", "ark:" + P("f.ark"), "ark:" + P("a.ark"),
                                                                         P("m.nnet"), out])
@@ -97,7 +111,8 @@ def main():
             (rc_r, err_r, out_r), (rc_o, err_o, out_o) = res["ref"], res["ours"]
             name = "case %d (%s)" % (case, ("forward, damaged features", "train, damaged features", "train, damaged alignments",
                                             "per-utterance trainer", "trainer towards targets, damaged features",
-                                            "trainer towards targets, damaged targets", "rbm trainer, damaged features")[what])
+                                            "trainer towards targets, damaged targets", "rbm trainer, damaged features",
+                                            "forward, damaged class frame counts")[what])
             kind = "both accept" if rc_r == 0 and rc_o == 0 else "both refuse" if rc_r != 0 and rc_o != 0 else "one refuses"
             why = []
             if rc_o not in (0, 1, 255, -6):
@@ -113,7 +128,7 @@ def main():
                 kind = "label outside the outputs: refused here only"
             elif kind == "one refuses":
                 why.append("status %s / %s" % (rc_r, rc_o))
-            elif what == 0:
+            elif what in (0, 7):
                 a, b = read_ark(out_r) if os.path.exists(out_r) else [], read_ark(out_o) if os.path.exists(out_o) else []
                 if a is None or b is None:
                     # the reference dies inside an entry now and then; whole entries are compared
@@ -128,7 +143,7 @@ def main():
                             if ka != kb or x.shape != y.shape or not np.allclose(x, y, rtol=1e-4, atol=1e-6, equal_nan=True):
                                 why.append("output %s / %s differs" % (ka, kb))
                                 break
-            elif kind == "both accept" and what != 6:
+            elif kind == "both accept" and what not in (6, 7):
                 la = [l for l in O.read_nnet(open(out_r, "rb").read()) if isinstance(l, O.BiasedLinearity)]
                 lb = [l for l in O.read_nnet(open(out_o, "rb").read()) if isinstance(l, O.BiasedLinearity)]
                 if any(not np.allclose(x.W, y.W, rtol=1e-3, atol=1e-5, equal_nan=True) for x, y in zip(la, lb)):
@@ -140,7 +155,7 @@ def main():
                 differ.append("%s: %s\n    ref : %s\n    ours: %s" % (name, "; ".join(why), err_r.strip().split("\n")[-1][:200] if err_r else "",
                                                                      err_o.strip().split("\n")[-1][:200] if err_o else ""))
                 os.makedirs(os.path.join(ROOT, "gpurun_out", "archive_mutation"), exist_ok=True)
-                for n in ("f.ark", "a.ark", "t.ark", "m.nnet"):
+                for n in ("f.ark", "a.ark", "t.ark", "m.nnet") + (("c.counts",) if what == 7 else ()):
                     open(os.path.join(ROOT, "gpurun_out", "archive_mutation", "case%d_%s" % (case, n)), "wb").write(open(P(n), "rb").read())
     lines = ["archive_mutation: %d cases, %d differ" % (args.cases, len(differ))]
     lines += ["  %-28s %d" % kv for kv in sorted(counts.items())] + differ
