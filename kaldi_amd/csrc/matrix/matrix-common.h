@@ -21,9 +21,10 @@ template <typename Real> class Matrix;
 template <typename Real>
 bool ReadBinaryFloats(std::istream &is, size_t n, size_t in_bytes, std::vector<Real> *out) {
   const size_t at_once = static_cast<size_t>(1) << 24;
-  out->clear();
+  if (n == 0) out->clear();
   std::vector<char> raw;
   size_t done = 0;
+  // (no clear() in front: a buffer that is read into again and again is only filled with zeros where it grows)
   while (done < n) {
     const size_t want = std::min(n - done, std::max(done, at_once));
     out->resize(done + want);

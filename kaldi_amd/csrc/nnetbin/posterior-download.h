@@ -163,7 +163,12 @@ class PosteriorWriter {
     const size_t cbytes = s->pieces.size() * 4 * sizeof(int32_t);
     CU_SAFE_CALL(hipK_memcpy_2d_async(stream_, s->host_counts, cbytes, s->dev_counts, cbytes, cbytes, 1, 1));
     const size_t pitch = s->stride * sizeof(BaseFloat);
-    CU_SAFE_CALL(hipK_memcpy_2d_async(stream_, s->host, pitch, s->dev, pitch, pitch, s->rows, 1));
+    // The host copy is dense (rows back to back) unless KALDI_AMD_PITCHED_DOWNLOAD is set: the writer then hands a
+    // whole utterance to the stream in one piece instead of gathering pitched rows into blocks first.
+    static const bool pitched = getenv("KALDI_AMD_PITCHED_DOWNLOAD") != NULL;
+    s->host_stride = pitched ? s->stride : s->cols;
+    const size_t hpitch = s->host_stride * sizeof(BaseFloat);
+    CU_SAFE_CALL(hipK_memcpy_2d_async(stream_, s->host, hpitch, s->dev, pitch, pitched ? pitch : hpitch, s->rows, 1));
     CU_SAFE_CALL(hipK_event_record(s->copied, stream_));
     std::lock_guard<std::mutex> l(mu_);
     queue_.push_back(s);
@@ -197,7 +202,7 @@ class PosteriorWriter {
     size_t dev_cap = 0, host_cap = 0;
     int32_t *dev_counts = NULL, *host_counts = NULL;  // per piece: NaN, +inf of the input; NaN, +inf of the output
     khEvent_t computed = NULL, copied = NULL;
-    int32 rows = 0, cols = 0, stride = 0;
+    int32 rows = 0, cols = 0, stride = 0, host_stride = 0;
     std::vector<Piece> pieces;
     CuMatrix<BaseFloat> view;
   };
@@ -219,7 +224,7 @@ class PosteriorWriter {
       if (cnt[1]) KALDI_ERR << "inf in features of : " << pc.key;
       if (cnt[2]) KALDI_ERR << "NaN in NNet output of : " << pc.key;
       if (cnt[3]) KALDI_ERR << "inf in NNet output of : " << pc.key;
-      const int32 rows = pc.rows, cols = s->cols, stride = s->stride;
+      const int32 rows = pc.rows, cols = s->cols, stride = s->host_stride;
       const BaseFloat *data = s->host + static_cast<size_t>(pc.row0) * stride;
       writer_.WriteWith(pc.key, [data, rows, cols, stride](std::ostream &os, bool binary) {
         InitKaldiOutputStream(os, binary);
